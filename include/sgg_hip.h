@@ -1,0 +1,134 @@
+/* libsgg_hip.so — C ABI of the MI355X-native (gfx950) Scene-Graph-GAN training hot path.
+ *
+ * The reference (mklawonn/Scene-Graph-GAN, Python 2 + TensorFlow 1.x) has NO FFI / plugin boundary: every
+ * arithmetic op is a stock TensorFlow kernel composed by architectures/*.py and train.py.  This header is the
+ * boundary a maintainer would bind instead of those TF kernels; each entry point cites the reference call
+ * site (file:line, relative to the reference root) whose TF op (and its autodiff gradient under
+ * optimizer.minimize, train.py:265-266) it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (sgg_last_error() gives the text); nothing throws,
+ *     allocates, or synchronises; work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - all pointers are DEVICE pointers to fp32 unless stated; tensors are dense row-major; activations are
+ *     NHWC, conv kernels HWIO [kh][kw][cin][cout] (TF layouts), dense kernels [in][out].
+ *   - `*_workspace_bytes` functions size the scratch buffer the caller must pass.
+ *   - "dual" pointer pairs: the second-order path of the gradient penalty runs the same kernels on dual
+ *     numbers (real plane, dual plane).  Passing NULL for the *_dual inputs selects plain fp32.
+ */
+#ifndef SGG_HIP_H
+#define SGG_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int sgg_version(void);
+const char* sgg_last_error(void);
+int sgg_device_info(int* cu_count, size_t* lds_bytes_per_cu, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- convolutional encoder: tf.layers.conv2d(padding="same") --------------------------------------------
+ * generator_with_attention.py:29-68, discriminator_with_attention.py:29-68 (12 live layers each).
+ * pad_t / pad_l are the TF SAME "before" pads (pad_total // 2); the "after" pad is implied by Ho/Wo. */
+int sgg_hwio_to_hwoi(const float* w_hwio, float* w_hwoi, int taps, int cin, int cout, void* stream);
+/* forward: `w` = HWIO kernel when Cin == 3, else its HWOI transpose (sgg_hwio_to_hwoi). y = conv(x) + bias */
+int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
+                        int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* stream);
+/* Conv2DBackpropInput: dx from dy and the HWIO kernel */
+int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
+                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* stream);
+/* Conv2DBackpropFilter: dw (HWIO) from x and dy */
+size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
+int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int Hi, int Wi, int Cin, int Ho,
+                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ---- tf.contrib.layers.layer_norm(activation_fn=tf.nn.elu) over (H,W,C) per sample ------------------------
+ * generator_with_attention.py:30..66 / discriminator_with_attention.py:30..66.  C: power of two in [4,1024].
+ * fwd writes a = ELU(LN(y)) and stats[b] = (mean, rstd).  bwd writes dy, dgamma, dbeta and (optional, may be
+ * NULL) dbias_prev = sum_{b,h,w} dy = the BiasAddGrad of the convolution that produced y. */
+size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C);
+int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats, int B,
+                              int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
+                              const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev, int B,
+                              int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- initial LSTM state: tf.reduce_mean(downsampled, axis=(1,2)) -------------------------------------------
+ * generator_with_attention.py:76-77.  Rows r in [0,R) use image r % B (R/B passes share one feature map). */
+int sgg_spatial_mean_fwd(const float* ctx, float* out_c, int ldc, float* out_h, int ldh, int R, int B, int L, int C,
+                         void* stream);
+int sgg_spatial_mean_bwd(const float* dc0, int ldc, const float* dh0, int ldh, float* dctx, int R, int B, int L, int C,
+                         int accumulate, void* stream);
+
+/* ---- dense contractions on f32 MFMA: tf.layers.dense / LSTM kernel matmul / tf.matmul(indices, W) ----------
+ * generator_with_attention.py:15,87,88; discriminator_with_attention.py:15,87,89,90.
+ *   fwd   C[M,N] (+)= A[M,K] B[K,N] (+ bias[N])
+ *   dgrad C[M,N] (+)= A[M,K] B[N,K]^T
+ *   wgrad C[M,N] (+)= A[K,M]^T B[K,N]
+ * Split-K partial slabs go to `workspace` (sgg_gemm_workspace_bytes). */
+size_t sgg_gemm_workspace_bytes(int M, int N, int K);
+int sgg_gemm_skinny_fwd(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        const float* bias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int sgg_gemm_skinny_dgrad(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                          int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int sgg_gemm_skinny_wgrad(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                          int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* the step-invariant part of the attention perceptron, ctx_flat[B, L*C] x W_ctx[L*C, L] (same kernels, named
+ * for the call site generator_with_attention.py:15) */
+int sgg_attn_ctx_gemm_fwd(int B, int L, int LC, const float* ctx_flat, const float* w_ctx, const float* bias, float* P,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int sgg_attn_ctx_gemm_dgrad(int B, int L, int LC, const float* dP, const float* w_ctx, float* dctx_flat, int accumulate,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int sgg_attn_ctx_gemm_wgrad(int B, int L, int LC, const float* ctx_flat, const float* dP, float* dw_ctx, int accumulate,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- attentionMechanism: score add -> softmax over L -> weighted sum of feature rows ------------------------
+ * generator_with_attention.py:13-18 / discriminator_with_attention.py:13-18.
+ *   e[r,:] = P[r % B,:] + ec[r,:]   (ec = c @ W_c, by sgg_gemm_skinny_fwd)
+ *   alpha = softmax(e);  z[r,:] = sum_l alpha[r,l] * ctx[r % B, l, :]
+ * bwd: de (cotangent of ec), dP[b,:] (+)= sum over its rows, dctx[b] (+)= alpha (x) dz.  With the *_dual
+ * pointers it is the dual-number evaluation used for the gradient-penalty term ("bwd2"). */
+int sgg_attn_step_fwd(const float* P, const float* ec, const float* ec_dual, int ldec, const float* ctx, float* alpha,
+                      float* alpha_dual, float* z, float* z_dual, int ldz, int R, int B, int L, int C, void* stream);
+int sgg_attn_step_bwd(const float* ctx, const float* alpha, const float* alpha_dual, const float* dz,
+                      const float* dz_dual, int lddz, float* de, float* de_dual, float* dP, float* dctx, int R, int B,
+                      int L, int C, int accumulate, void* stream);
+
+/* ---- tf.contrib.rnn.LayerNormBasicLSTMCell(512) pointwise part ---------------------------------------------
+ * generator_with_attention.py:79,87 / discriminator_with_attention.py:81,89.  gates = [x,h] @ kernel, [R,2048] in
+ * the order i, j, f, o.  ln_params = [10][512]: gamma,beta of scopes input, transform, forget, output, state.
+ * One wave per row; wave-level reductions for the five LayerNorms. pgrad: [R][10][512] per-row LN-parameter
+ * gradients (sum the rows with sgg_colsum). */
+int sgg_lnlstm_gates_fwd(const float* gates, const float* gates_dual, const float* c_prev, const float* c_prev_dual,
+                         const float* ln_params, float* c_new, float* c_new_dual, float* h_new, float* h_new_dual,
+                         int ldh, int R, void* stream);
+int sgg_lnlstm_gates_bwd(const float* gates, const float* gates_dual, const float* c_prev, const float* c_prev_dual,
+                         const float* ln_params, const float* dh, const float* dh_dual, int lddh, const float* dc_new,
+                         const float* dc_new_dual, float* dgates, float* dgates_dual, float* dc_prev,
+                         float* dc_prev_dual, float* pgrad, int R, void* stream);
+int sgg_colsum(const float* X, int rows, int cols, int ld, float* out, int accumulate, void* stream);
+
+/* ---- WGAN-GP loss: tf.contrib.gan.gan_loss(wasserstein_*, gradient_penalty_weight, one_sided) ---------------
+ * train.py:245-250 */
+int sgg_onehot(const long long* labels, float* out, int rows, int V, void* stream);            /* train.py:173 */
+int sgg_interpolate(const float* real, const float* fake, const float* alpha, float* out, int B, int n, void* stream);
+int sgg_wgan_gp_loss_fwd(const float* g, float* slopes, float* pen, int B, int n, void* stream);
+int sgg_wgan_gp_loss_bwd(const float* g, const float* slopes, const float* pen, float* v, int B, int n, float scale,
+                         void* stream);
+/* out4 = { disc_cost, wasserstein distance term, gradient penalty, mean D(fake) }  (gen_cost = -out4[3]) */
+int sgg_wgan_losses(const float* d_out, const float* pen, float lam, int B, int T, int has_real, float* out4, void* stream);
+
+/* ---- tf.train.AdamOptimizer(1e-4, beta1=0.5, beta2=0.9).minimize: train.py:258-266 ---------------------------
+ * lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller; theta -= lr_t*m/(sqrt(v)+eps). */
+int sgg_adam_tf_multi(float* params, const float* grads, float* m, float* v, long long n, float lr_t, float beta1,
+                      float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- tf.argmax(x, axis=-1): train.py:270-271 ---------------------------------------------------------------- */
+int sgg_argmax_rows(const float* x, long long* out, int rows, int V, int ld, void* stream);
+
+int sgg_fill(float* p, long long n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGG_HIP_H */

@@ -1,0 +1,318 @@
+// Implicit-GEMM "gather" convolution on f32 MFMA for NHWC tensors (gfx950).
+//
+// One kernel serves both
+//   * forward   tf.layers.conv2d(padding="same")          reference: architectures/generator_with_attention.py:29-68
+//   * dgrad     Conv2DBackpropInput (autodiff of the same) reference: train.py:265-266 (optimizer.minimize)
+// through the parameterisation
+//   out[b, y*osy+ooy, x*osx+oox, n] = bias[n] + sum_{th,tw} sum_c src[b, y*sy+oy+th*dy, x*sx+ox+tw*dx, c] * wm[tap(th,tw)][n][c]
+// over a "virtual" output grid [B, Hm, Wm] per class (stride-2 dgrad = 4 parity classes, each a stride-1
+// correlation with a sub-sampled kernel; forward = 1 class).  Out-of-range source pixels contribute zero
+// (TF SAME padding, incl. the asymmetric (1,2) case).  Weights are [tap][n][c] with c contiguous:
+// forward uses the HWOI transpose made by sgg_hwio_to_hwoi, dgrad uses the HWIO tensor as it is.
+//
+// Tiling: workgroup = 256 threads = 4 waves; tile BM x BN x 32(k); A (gathered pixels) and B (weights) are
+// staged global -> registers -> LDS (KC layout, see mma_f32.h) with the next slab's global loads in flight
+// while the current slab is contracted (register prefetch, one LDS buffer).
+#include "mma_f32.h"
+
+struct GatherClass {
+  int Hm, Wm, M;        // virtual grid and B*Hm*Wm
+  int nth, ntw;         // taps in this class
+  int oy, ox;           // source offset
+  int kh0, kw0, kstep;  // weight tap index = (kh0 + kstep*th)*KW + (kw0 + kstep*tw)
+  int ooy, oox;         // output offset
+  int mtiles;
+};
+
+struct GatherParams {
+  const float* src;
+  const float* wm;
+  const float* bias;  // may be null
+  float* out;
+  int B, Hs, Ws, C;  // source grid, channels (= contraction length per tap), C % 32 == 0
+  int N;             // output channels, N % 32 == 0
+  int Ho, Wo;        // full output grid
+  int sy, sx, dy, dx, osy, osx, KW;
+  int ncls;
+  GatherClass cls[4];
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_gather_kernel(GatherParams p) {
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NPA = BM * 8 / 256, NPB = (BN * 8 + 255) / 256;
+  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile");
+
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * SGG_LDK + BM];
+  float* A_s = lds;
+  float* B_s = lds + BM * SGG_LDK;
+  int* out_off_s = reinterpret_cast<int*>(lds + (BM + BN) * SGG_LDK);
+
+  const GatherClass& c = p.cls[blockIdx.y];
+  const int ntiles_n = p.N / BN;
+  const int nwg = c.mtiles * ntiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int mt = lid / ntiles_n, nt = lid % ntiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+
+  // ---- per-thread gather rows -----------------------------------------------------------------
+  const int col4 = tid & 7;
+  int a_ys[NPA], a_xs[NPA], a_base[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int m = m0 + (tid >> 3) + 32 * j;
+    if (m < c.M) {
+      const int x = m % c.Wm;
+      const int t = m / c.Wm;
+      const int y = t % c.Hm;
+      const int b = t / c.Hm;
+      a_ys[j] = y * p.sy + c.oy;
+      a_xs[j] = x * p.sx + c.ox;
+      a_base[j] = b * p.Hs * p.Ws * p.C + col4 * 4;
+    } else {
+      a_ys[j] = -(1 << 28);  // never in range
+      a_xs[j] = 0;
+      a_base[j] = 0;
+    }
+  }
+  // output row offsets (element offset of channel 0, or -1) for the epilogue
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < c.M) {
+      const int x = m % c.Wm;
+      const int t = m / c.Wm;
+      const int y = t % c.Hm;
+      const int b = t / c.Hm;
+      off = ((b * p.Ho + y * p.osy + c.ooy) * p.Wo + x * p.osx + c.oox) * p.N;
+    }
+    out_off_s[r] = off;
+  }
+
+  f32x16 acc[TM][TN];
+  acc_zero<TM, TN>(acc);
+
+  const int cchunks = p.C >> 5;
+  const int n_iters = c.nth * c.ntw * cchunks;
+
+  f32x4 ra[NPA], rb[NPB];
+  auto issue_loads = [&](int it) {
+    const int tap = it / cchunks;
+    const int c0 = (it - tap * cchunks) << 5;
+    const int th = tap / c.ntw, tw = tap - th * c.ntw;
+    const int ty = th * p.dy, tx = tw * p.dx;
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int yy = a_ys[j] + ty, xx = a_xs[j] + tx;
+      const bool ok = (unsigned)yy < (unsigned)p.Hs && (unsigned)xx < (unsigned)p.Ws;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.src + (size_t)(a_base[j] + (yy * p.Ws + xx) * p.C + c0));
+      ra[j] = v;
+    }
+    const float* wtap = p.wm + (size_t)((c.kh0 + c.kstep * th) * p.KW + (c.kw0 + c.kstep * tw)) * p.N * p.C;
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < BN) v = *reinterpret_cast<const f32x4*>(wtap + (size_t)(n0 + row) * p.C + c0 + col4 * 4);
+      rb[j] = v;
+    }
+  };
+
+  issue_loads(0);
+  for (int it = 0; it < n_iters; ++it) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPA; ++j)
+      *reinterpret_cast<f32x4*>(A_s + ((tid >> 3) + 32 * j) * SGG_LDK + col4 * 4) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      if (row < BN) *reinterpret_cast<f32x4*>(B_s + row * SGG_LDK + col4 * 4) = rb[j];
+    }
+    __syncthreads();
+    if (it + 1 < n_iters) issue_loads(it + 1);
+    mma_slab_kc_kc<TM, TN>(A_s, B_s, wm0, wn0, lane, acc);
+  }
+
+  // ---- epilogue: + bias, scatter rows ----------------------------------------------------------
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn0 + tn * 32 + acc_col(lane);
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + tm * 32 + acc_row(r, lane);
+        const int off = out_off_s[row];
+        if (off >= 0) p.out[(size_t)off + n] = acc[tm][tn][r] + bv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cin = 3 forward (conv1_1, generator_with_attention.py:29): K = 27, HBM-bound on the 32-channel output.
+// 8 lanes per output pixel, 4 output channels each -> a wave stores 1 KiB contiguous per instruction.
+// Weights are HWIO [3][3][3][Cout] read through LDS.
+// ---------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                          int H, int W, int pt, int pl) {
+  constexpr int LPP = COUT / 4;  // lanes per pixel
+  constexpr int PPB = 256 / LPP;
+  __shared__ __attribute__((aligned(16))) float w_s[27 * COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) w_s[i] = w[i];
+  __syncthreads();
+  const int sub = threadIdx.x % LPP, pl_ = threadIdx.x / LPP;
+  const long long npix = (long long)B * H * W;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + sub * 4);
+  for (long long pix = (long long)blockIdx.x * PPB + pl_; pix < npix; pix += (long long)gridDim.x * PPB) {
+    const int xw = (int)(pix % W);
+    const long long t = pix / W;
+    const int yh = (int)(t % H);
+    const int b = (int)(t / H);
+    f32x4 acc = bv;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int yy = yh + kh - pt;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int xx = xw + kw - pl;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          const float* px = x + ((size_t)(b * H + yy) * W + xx) * 3;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) {
+            const float v = px[ci];
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w_s + ((kh * 3 + kw) * 3 + ci) * COUT + sub * 4);
+            acc += v * wv;
+          }
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * COUT + sub * 4) = acc;
+  }
+}
+
+// HWIO [taps][cin][cout] -> HWOI [taps][cout][cin]
+__global__ void hwio_to_hwoi_kernel(const float* __restrict__ w, float* __restrict__ wt, int taps, int cin, int cout) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    tile[r][tx] = (ci < cin && co < cout) ? w[((size_t)tap * cin + ci) * cout + co] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    if (ci < cin && co < cout) wt[((size_t)tap * cout + co) * cin + ci] = tile[tx][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN>
+static void launch_gather(const GatherParams& p, hipStream_t st) {
+  int maxwg = 0;
+  GatherParams q = p;
+  for (int i = 0; i < q.ncls; ++i) {
+    q.cls[i].mtiles = sgg_cdiv(q.cls[i].M, BM);
+    const int nwg = q.cls[i].mtiles * (q.N / BN);
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  dim3 grid(maxwg, q.ncls, 1);
+  hipLaunchKernelGGL((conv_gather_kernel<BM, BN, WGM, WGN>), grid, dim3(256), 0, st, q);
+}
+
+static int dispatch_gather(const GatherParams& p, hipStream_t st) {
+  if (p.N % 128 == 0)
+    launch_gather<128, 128, 2, 2>(p, st);
+  else if (p.N % 64 == 0)
+    launch_gather<256, 64, 4, 1>(p, st);
+  else
+    launch_gather<256, 32, 4, 1>(p, st);
+  return SGG_OK;
+}
+
+extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, int cout, void* stream) {
+  SGG_CHECK_ARG(w && wt && taps > 0 && cin > 0 && cout > 0, "sgg_hwio_to_hwoi: bad argument");
+  dim3 grid(sgg_cdiv(cout, 32), sgg_cdiv(cin, 32), taps);
+  hipLaunchKernelGGL(hwio_to_hwoi_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, taps, cin, cout);
+  SGG_LAUNCH_CHECK("sgg_hwio_to_hwoi");
+  return SGG_OK;
+}
+
+// Forward. `w` is the HWIO kernel for Cin == 3 and the HWOI transpose (sgg_hwio_to_hwoi) otherwise.
+extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi,
+                                   int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
+                                   void* stream) {
+  SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
+  SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_fwd: bad dims");
+  SGG_CHECK_ARG(Ho == (Hi + stride - 1) / stride && Wo == (Wi + stride - 1) / stride,
+                "sgg_conv2d_nhwc_fwd: Ho/Wo must be ceil(in/stride) (SAME padding)");
+  SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
+                "sgg_conv2d_nhwc_fwd: tensor exceeds 2^31 elements");
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 3) {
+    SGG_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && Cout == 32, "sgg_conv2d_nhwc_fwd: Cin=3 path needs 3x3 s1 Cout=32");
+    const long long npix = (long long)B * Ho * Wo;
+    const int grid = (int)((npix + 31) / 32 < 8192 ? (npix + 31) / 32 : 8192);
+    hipLaunchKernelGGL(conv_c3_fwd_kernel<32>, dim3(grid), dim3(256), 0, st, x, w, bias, y, B, Hi, Wi, pad_t, pad_l);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(c3)");
+    return SGG_OK;
+  }
+  SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_fwd: Cin and Cout must be multiples of 32 (or Cin == 3)");
+  GatherParams p;
+  p.src = x; p.wm = w; p.bias = bias; p.out = y;
+  p.B = B; p.Hs = Hi; p.Ws = Wi; p.C = Cin; p.N = Cout; p.Ho = Ho; p.Wo = Wo;
+  p.sy = stride; p.sx = stride; p.dy = 1; p.dx = 1; p.osy = 1; p.osx = 1; p.KW = KW;
+  p.ncls = 1;
+  GatherClass& c = p.cls[0];
+  c.Hm = Ho; c.Wm = Wo; c.M = B * Ho * Wo; c.nth = KH; c.ntw = KW; c.oy = -pad_t; c.ox = -pad_l;
+  c.kh0 = 0; c.kw0 = 0; c.kstep = 1; c.ooy = 0; c.oox = 0; c.mtiles = 0;
+  dispatch_gather(p, st);
+  SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd");
+  return SGG_OK;
+}
+
+// dgrad: dx[B,Hi,Wi,Cin] = conv-transpose of dy[B,Ho,Wo,Cout] with the HWIO kernel w (no bias).
+extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
+                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* stream) {
+  SGG_CHECK_ARG(dy && w && dx, "sgg_conv2d_nhwc_dgrad: null pointer");
+  SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_dgrad: bad dims");
+  SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_dgrad: Cin and Cout must be multiples of 32");
+  SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
+                "sgg_conv2d_nhwc_dgrad: tensor exceeds 2^31 elements");
+  GatherParams p;
+  p.src = dy; p.wm = w; p.bias = nullptr; p.out = dx;
+  p.B = B; p.Hs = Ho; p.Ws = Wo; p.C = Cout; p.N = Cin; p.Ho = Hi; p.Wo = Wi;
+  p.sy = 1; p.sx = 1; p.dy = -1; p.dx = -1; p.osy = stride; p.osx = stride; p.KW = KW;
+  p.ncls = stride * stride;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      GatherClass& c = p.cls[ph * stride + pw];
+      const int kh0 = (ph + pad_t) % stride, kw0 = (pw + pad_l) % stride;
+      c.Hm = (Hi - ph + stride - 1) / stride;
+      c.Wm = (Wi - pw + stride - 1) / stride;
+      c.M = B * c.Hm * c.Wm;
+      c.nth = (KH - kh0 + stride - 1) / stride;
+      c.ntw = (KW - kw0 + stride - 1) / stride;
+      c.oy = (ph + pad_t - kh0) / stride;
+      c.ox = (pw + pad_l - kw0) / stride;
+      c.kh0 = kh0; c.kw0 = kw0; c.kstep = stride; c.ooy = ph; c.oox = pw; c.mtiles = 0;
+    }
+  dispatch_gather(p, (hipStream_t)stream);
+  SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad");
+  return SGG_OK;
+}

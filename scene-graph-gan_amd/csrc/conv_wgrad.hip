@@ -1,0 +1,289 @@
+// Conv2DBackpropFilter on f32 MFMA (gfx950): dW[kh][kw][ci][co] = sum_{b,ho,wo} x[b, ho*s-pt+kh, wo*s-pl+kw, ci] * dy[b,ho,wo,co]
+// Reference: autodiff of tf.layers.conv2d (architectures/generator_with_attention.py:29-68) under
+// optimizer.minimize (train.py:265-266).
+//
+// Per tap this is a GEMM  dW_tap[ci][co] = X_tap^T[ci][pix] * dY[pix][co]  whose contraction runs over
+// B*Ho*Wo pixels (up to 3.2 M).  Decomposition: grid = (ci-tile x co-tile, tap, pixel split); each
+// workgroup streams its pixel range in 32-pixel slabs (both operands are rows of contiguous channels, so
+// the LDS tiles are in MC layout, mma_f32.h) and writes an f32 partial slab; a second kernel sums the
+// slabs in a fixed order (deterministic, no atomics).
+#include "mma_f32.h"
+
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  float* out;  // [nsplit][taps][Cin][Cout]
+  int B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l;
+  int Mpix, chunk, ntile_n;
+};
+
+template <int BMC, int BNC, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+  constexpr int WGM = BMC / WM, WGN = BNC / WN, WGK = 4 / (WGM * WGN);
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NPA = BMC / 32, NPB = BNC / 32;
+  constexpr int KROWS = 32 / WGK;
+  constexpr int TILE_FLOATS = 32 * (BMC + BNC);
+  constexpr int RED_FLOATS = (WGK > 1) ? 4 * TM * TN * 16 * 64 : 0;
+  constexpr int LDS_FLOATS = TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS;
+  static_assert(WGM * WGN * WGK == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* A_s = lds;
+  float* B_s = lds + 32 * BMC;
+
+  const int tile = blockIdx.x;
+  const int ci0 = (tile / p.ntile_n) * BMC, co0 = (tile % p.ntile_n) * BNC;
+  const int tap = blockIdx.y;
+  const int kh = tap / p.KW, kw = tap % p.KW;
+  const int split = blockIdx.z;
+  const int pix_begin = split * p.chunk;
+  const int pix_end = min(pix_begin + p.chunk, p.Mpix);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WGM * WGN);
+  const int wmi = (wave / WGN) % WGM, wni = wave % WGN;
+  const int wm0 = wmi * WM, wn0 = wni * WN;
+
+  f32x16 acc[TM][TN];
+  acc_zero<TM, TN>(acc);
+
+  constexpr int A_CPR = BMC / 4, B_CPR = BNC / 4;  // float4 per row
+  f32x4 ra[NPA], rb[NPB];
+  auto issue_loads = [&](int pix0) {
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int pi = tid + 256 * j;
+      const int row = pi / A_CPR, c4 = pi % A_CPR;
+      const int pix = pix0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < pix_end) {
+        const int wo = pix % p.Wo;
+        const int t = pix / p.Wo;
+        const int ho = t % p.Ho;
+        const int b = t / p.Ho;
+        const int yy = ho * p.stride - p.pad_t + kh, xx = wo * p.stride - p.pad_l + kw;
+        if ((unsigned)yy < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi)
+          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(b * p.Hi + yy) * p.Wi + xx) * p.Cin + ci0 + c4 * 4);
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const int pi = tid + 256 * j;
+      const int row = pi / B_CPR, c4 = pi % B_CPR;
+      const int pix = pix0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < pix_end) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)pix * p.Cout + co0 + c4 * 4);
+      rb[j] = v;
+    }
+  };
+
+  if (pix_begin < pix_end) issue_loads(pix_begin);
+  for (int pix0 = pix_begin; pix0 < pix_end; pix0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) *reinterpret_cast<f32x4*>(A_s + (tid + 256 * j) * 4) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) *reinterpret_cast<f32x4*>(B_s + (tid + 256 * j) * 4) = rb[j];
+    __syncthreads();
+    if (pix0 + 32 < pix_end) issue_loads(pix0 + 32);
+    mma_slab_mc_mc<TM, TN>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
+  }
+
+  if constexpr (WGK > 1) {
+    // reduce the k-split waves through LDS: red[wave][slot][lane]
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * TM * TN * 16 + (tm * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+    __syncthreads();
+    if (wk != 0) return;
+#pragma unroll
+    for (int k = 1; k < WGK; ++k) {
+      const int w2 = wave + k * WGM * WGN;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tm][tn][r] += red[(w2 * TM * TN * 16 + (tm * TN + tn) * 16 + r) * 64 + lane];
+    }
+  }
+
+  float* o = p.out + ((size_t)split * p.KH * p.KW + tap) * p.Cin * p.Cout;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wm0 + tm * 32 + acc_row(r, lane);
+        const int co = co0 + wn0 + tn * 32 + acc_col(lane);
+        o[(size_t)ci * p.Cout + co] = acc[tm][tn][r];
+      }
+}
+
+// out[e] = sum_s slabs[s][e]   (fixed order -> deterministic)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4, int nsplit) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
+  for (int k = 1; k < nsplit; ++k) s += reinterpret_cast<const f32x4*>(slabs)[(long long)k * n4 + i];
+  reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cin = 3 (conv1_1): dW[27][32] over up to 3.2 M pixels. One workgroup per pixel chunk, 216 active
+// threads, thread (k, co4) keeps 4 accumulators; dy rows and the 27-value patches go through LDS.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ slabs, int B, int H, int W, int pt, int pl,
+                                                            int chunk) {
+  constexpr int P = 64;  // pixels per slab
+  __shared__ __attribute__((aligned(16))) float dy_s[P * 32];
+  __shared__ float xp_s[P * 28];
+  const int tid = threadIdx.x;
+  const int npix = B * H * W;
+  const int pix_begin = blockIdx.x * chunk, pix_end = min(pix_begin + chunk, npix);
+  const int k = tid >> 3, co4 = tid & 7;  // k in 0..31 (27 used)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int pix0 = pix_begin; pix0 < pix_end; pix0 += P) {
+    __syncthreads();
+    // dy tile: P*32 floats = 512 float4 -> 2 per thread
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pi = tid + 256 * j;
+      const int pix = pix0 + (pi >> 3);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < pix_end) v = *reinterpret_cast<const f32x4*>(dy + (size_t)pix * 32 + (pi & 7) * 4);
+      *reinterpret_cast<f32x4*>(dy_s + pi * 4) = v;
+    }
+    // patches: P*27 scalars
+    for (int e = tid; e < P * 27; e += 256) {
+      const int pr = e / 27, kk = e % 27;
+      const int pix = pix0 + pr;
+      float v = 0.f;
+      if (pix < pix_end) {
+        const int xw = pix % W;
+        const int t = pix / W;
+        const int yh = t % H;
+        const int b = t / H;
+        const int tap = kk / 3, ci = kk % 3;
+        const int yy = yh + tap / 3 - pt, xx = xw + tap % 3 - pl;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[((size_t)(b * H + yy) * W + xx) * 3 + ci];
+      }
+      xp_s[pr * 28 + kk] = v;
+    }
+    __syncthreads();
+    if (k < 27) {
+#pragma unroll 8
+      for (int pr = 0; pr < P; ++pr) {
+        const float xv = xp_s[pr * 28 + k];
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy_s + pr * 32 + co4 * 4);
+        acc += xv * dv;
+      }
+    }
+  }
+  if (k < 27) *reinterpret_cast<f32x4*>(slabs + (size_t)blockIdx.x * 27 * 32 + k * 32 + co4 * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------
+struct WgradPlan {
+  int bmc, bnc, tiles, nsplit, chunk;
+  size_t ws_bytes;
+};
+
+static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+  WgradPlan pl;
+  const long long mpix = (long long)B * Ho * Wo;
+  if (Cin == 3) {
+    pl.bmc = 27; pl.bnc = 32; pl.tiles = 1;
+    int ns = (int)((mpix + 2047) / 2048);
+    if (ns > 2048) ns = 2048;
+    if (ns < 1) ns = 1;
+    pl.chunk = (int)(((mpix + ns - 1) / ns + 63) / 64 * 64);
+    pl.nsplit = (int)((mpix + pl.chunk - 1) / pl.chunk);
+    pl.ws_bytes = (size_t)pl.nsplit * 27 * 32 * sizeof(float);
+    return pl;
+  }
+  pl.bmc = Cin >= 128 ? 128 : Cin;
+  pl.bnc = Cout >= 128 ? 128 : Cout;
+  pl.tiles = (Cin / pl.bmc) * (Cout / pl.bnc);
+  const int base = pl.tiles * KH * KW;
+  int ns = (1536 + base - 1) / base;
+  const long long max_ns = mpix / 512 > 0 ? mpix / 512 : 1;
+  if (ns > max_ns) ns = (int)max_ns;
+  if (ns < 1) ns = 1;
+  pl.chunk = (int)(((mpix + ns - 1) / ns + 31) / 32 * 32);
+  pl.nsplit = (int)((mpix + pl.chunk - 1) / pl.chunk);
+  pl.ws_bytes = pl.nsplit > 1 ? (size_t)pl.nsplit * KH * KW * Cin * Cout * sizeof(float) : 0;
+  return pl;
+}
+
+extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH,
+                                                        int KW) {
+  (void)Hi; (void)Wi;
+  return wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW).ws_bytes;
+}
+
+extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,
+                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  SGG_CHECK_ARG(x && dy && dw, "sgg_conv2d_nhwc_wgrad: null pointer");
+  SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_wgrad: bad dims");
+  SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
+                "sgg_conv2d_nhwc_wgrad: tensor exceeds 2^31 elements");
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan pl = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW);
+  if (pl.ws_bytes > 0) {
+    if (!workspace || workspace_bytes < pl.ws_bytes) {
+      sgg_set_error("sgg_conv2d_nhwc_wgrad: workspace too small (%zu < %zu)", workspace_bytes, pl.ws_bytes);
+      return SGG_ERR_WORKSPACE;
+    }
+  }
+  const long long nout = (long long)KH * KW * Cin * Cout;
+  if (Cin == 3) {
+    SGG_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && Cout == 32, "sgg_conv2d_nhwc_wgrad: Cin=3 path needs 3x3 s1 Cout=32");
+    hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, B, Hi, Wi, pad_t,
+                       pad_l, pl.chunk);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3)");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sgg_cdiv(nout / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                       nout / 4, pl.nsplit);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3 reduce)");
+    return SGG_OK;
+  }
+  SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_wgrad: Cin and Cout must be multiples of 32 (or Cin == 3)");
+  SGG_CHECK_ARG(pl.bmc == 32 || pl.bmc == 64 || pl.bmc == 128, "sgg_conv2d_nhwc_wgrad: unsupported Cin tile");
+  SGG_CHECK_ARG(pl.bnc == 32 || pl.bnc == 64 || pl.bnc == 128, "sgg_conv2d_nhwc_wgrad: unsupported Cout tile");
+  WgradParams p;
+  p.x = x; p.dy = dy; p.out = pl.nsplit > 1 ? (float*)workspace : dw;
+  p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW;
+  p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.Mpix = B * Ho * Wo; p.chunk = pl.chunk; p.ntile_n = Cout / pl.bnc;
+  dim3 grid(pl.tiles, KH * KW, pl.nsplit);
+#define SGG_WG(BMC, BNC, WM, WN) \
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN>), grid, dim3(256), 0, st, p)
+  if (pl.bmc == 32 && pl.bnc == 32) SGG_WG(32, 32, 32, 32);
+  else if (pl.bmc == 32 && pl.bnc == 64) SGG_WG(32, 64, 32, 32);
+  else if (pl.bmc == 64 && pl.bnc == 32) SGG_WG(64, 32, 32, 32);
+  else if (pl.bmc == 64 && pl.bnc == 64) SGG_WG(64, 64, 32, 32);
+  else if (pl.bmc == 32 && pl.bnc == 128) SGG_WG(32, 128, 32, 32);
+  else if (pl.bmc == 128 && pl.bnc == 32) SGG_WG(128, 32, 32, 32);
+  else if (pl.bmc == 64 && pl.bnc == 128) SGG_WG(64, 128, 32, 64);
+  else if (pl.bmc == 128 && pl.bnc == 64) SGG_WG(128, 64, 64, 32);
+  else SGG_WG(128, 128, 64, 64);
+#undef SGG_WG
+  SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad");
+  if (pl.nsplit > 1) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sgg_cdiv(nout / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                       nout / 4, pl.nsplit);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(reduce)");
+  }
+  return SGG_OK;
+}

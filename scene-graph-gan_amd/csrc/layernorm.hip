@@ -1,0 +1,348 @@
+// tf.contrib.layers.layer_norm(x, activation_fn=tf.nn.elu) over (H,W,C) per sample, gamma/beta [C], eps = 1e-12
+// Reference: architectures/generator_with_attention.py:30..66 (13 call sites, 11 live), same lines in the
+// discriminator; TF semantics SURVEY.md Appendix A.2 (biased two-pass variance, batch_normalization form).
+//
+// HBM-bound streaming kernels (float4 per lane, grid-stride chunks of 4096 elements). The per-sample
+// reduction spans many workgroups; partial (count, mean, M2) triples are merged with Chan's formula by
+// every consumer workgroup (no atomics, deterministic, numerically equal to the two-pass variance).
+//
+//   forward : ln_stats_partial  -> ln_apply_elu
+//   backward: ln_bwd_partial    -> ln_bwd_finalize (dgamma, dbeta, bias grad of the producing conv)
+//                               -> ln_bwd_apply    (dy)
+#include "sgg_common.h"
+
+#define LN_EPS 1e-12f
+#define LN_CHUNK 4096  // elements per workgroup iteration: 256 threads x 4 x float4
+
+struct LnGeom {
+  int B, C;
+  long long N;   // elements per sample = HW * C
+  int HW;
+  int G;         // workgroups per sample
+  int cpg;       // chunks per workgroup
+};
+
+static LnGeom ln_geom(int B, int HW, int C) {
+  LnGeom g;
+  g.B = B; g.C = C; g.HW = HW; g.N = (long long)HW * C;
+  const int nchunks = (int)((g.N + LN_CHUNK - 1) / LN_CHUNK);
+  int G = (1536 + B - 1) / B;
+  if (G > nchunks) G = nchunks;
+  if (G < 1) G = 1;
+  g.cpg = (nchunks + G - 1) / G;
+  g.G = (nchunks + g.cpg - 1) / g.cpg;
+  return g;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
+                                                               long long N, int G, int cpg) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, g = blockIdx.x;
+  const float* yb = y + (size_t)b * N;
+  float n_run = 0.f, mean_run = 0.f, m2_run = 0.f;
+  for (int c = 0; c < cpg; ++c) {
+    const long long base = ((long long)g * cpg + c) * LN_CHUNK;
+    if (base >= N) break;
+    f32x4 v[4];
+    float s = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = base + (threadIdx.x + 256 * j) * 4;
+      if (e < N) {
+        v[j] = *reinterpret_cast<const f32x4*>(yb + e);
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        cnt += 4;
+      } else {
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float n_c = (float)((N - base) < LN_CHUNK ? (N - base) : LN_CHUNK);
+    const float mean_c = block_sum_256(s, red) / n_c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = base + (threadIdx.x + 256 * j) * 4;
+      if (e < N) {
+        const f32x4 d = v[j] - mean_c;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+    }
+    const float m2_c = block_sum_256(q, red);
+    const float n_new = n_run + n_c;
+    const float delta = mean_c - mean_run;
+    mean_run += delta * (n_c / n_new);
+    m2_run += m2_c + delta * delta * (n_run * n_c / n_new);
+    n_run = n_new;
+  }
+  if (threadIdx.x == 0) {
+    float* o = part + ((size_t)b * G + g) * 3;
+    o[0] = n_run; o[1] = mean_run; o[2] = m2_run;
+  }
+}
+
+// merge G partials of sample b -> (mean, rstd); every thread returns the same values
+__device__ __forceinline__ void ln_merge(const float* __restrict__ part, int G, float N, float* red, float& mean,
+                                         float& rstd) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) s += part[i * 3 + 0] * part[i * 3 + 1];
+  mean = block_sum_256(s, red) / N;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) {
+    const float d = part[i * 3 + 1] - mean;
+    q += part[i * 3 + 2] + part[i * 3 + 0] * d * d;
+  }
+  const float var = block_sum_256(q, red) / N;
+  rstd = rsqrtf(var + LN_EPS);
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+__global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ part,
+                                                           float* __restrict__ a, float* __restrict__ stats, long long N,
+                                                           int C, int G, int cpg) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, g = blockIdx.x;
+  float mean, rstd;
+  ln_merge(part + (size_t)b * G * 3, G, (float)N, red, mean, rstd);
+  if (g == 0 && threadIdx.x == 0) {
+    stats[b * 2 + 0] = mean;
+    stats[b * 2 + 1] = rstd;
+  }
+  const float* yb = y + (size_t)b * N;
+  float* ab = a + (size_t)b * N;
+  const int ch = (threadIdx.x * 4) % C;   // constant across chunks: LN_CHUNK and 1024 are multiples of C
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + ch);
+  const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + ch);
+  const f32x4 inv = gm * rstd;
+  const f32x4 shift = bt - inv * mean;
+  for (int c = 0; c < cpg; ++c) {
+    const long long base = ((long long)g * cpg + c) * LN_CHUNK;
+    if (base >= N) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = base + (threadIdx.x + 256 * j) * 4;
+      if (e < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(yb + e);
+        f32x4 o = v * inv + shift;
+        o[0] = elu1(o[0]); o[1] = elu1(o[1]); o[2] = elu1(o[2]); o[3] = elu1(o[3]);
+        *reinterpret_cast<f32x4*>(ab + e) = o;
+      }
+    }
+  }
+}
+
+// ---- backward ----------------------------------------------------------------------------------------
+// per workgroup: sspart[b][g] = (sum dxhat, sum dxhat*xhat); chpart[b][g][3][C] = (sum dn, sum dn*xhat, sum xhat)
+__global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __restrict__ y, const float* __restrict__ da,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ stats, float* __restrict__ sspart,
+                                                             float* __restrict__ chpart, long long N, int C, int G, int cpg) {
+  __shared__ float red[4];
+  __shared__ float chs[256 * 12];
+  const int b = blockIdx.y, g = blockIdx.x;
+  const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
+  const float* yb = y + (size_t)b * N;
+  const float* db = da + (size_t)b * N;
+  const int ch = (threadIdx.x * 4) % C;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + ch);
+  const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + ch);
+  f32x4 sA = {0.f, 0.f, 0.f, 0.f}, sB = sA, sX = sA;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < cpg; ++c) {
+    const long long base = ((long long)g * cpg + c) * LN_CHUNK;
+    if (base >= N) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = base + (threadIdx.x + 256 * j) * 4;
+      if (e < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(yb + e);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(db + e);
+        const f32x4 xh = (v - mean) * rstd;
+        const f32x4 n = xh * gm + bt;
+        f32x4 dn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dn[q] = d[q] * (n[q] > 0.f ? 1.f : __expf(n[q]));
+        const f32x4 dxh = dn * gm;
+        sA += dn; sB += dn * xh; sX += xh;
+        s1 += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
+        const f32x4 t = dxh * xh;
+        s2 += (t[0] + t[1]) + (t[2] + t[3]);
+      }
+    }
+  }
+  const float S1 = block_sum_256(s1, red);
+  const float S2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    sspart[((size_t)b * G + g) * 2 + 0] = S1;
+    sspart[((size_t)b * G + g) * 2 + 1] = S2;
+  }
+  // per-channel reduce across threads with equal (tid*4) % C
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    chs[threadIdx.x * 12 + q] = sA[q];
+    chs[threadIdx.x * 12 + 4 + q] = sB[q];
+    chs[threadIdx.x * 12 + 8 + q] = sX[q];
+  }
+  __syncthreads();
+  const int tpc = C / 4;                 // distinct thread classes (C <= 1024)
+  const int reps = 256 / tpc;            // threads per class (>= 1 when C <= 1024)
+  float* o = chpart + ((size_t)b * G + g) * 3 * C;
+  for (int item = threadIdx.x; item < 3 * C; item += 256) {
+    const int which = item / C, cc = item % C;
+    const int t0 = cc / 4, q = cc % 4;
+    float s = 0.f;
+    if (reps >= 1)
+      for (int r = 0; r < reps; ++r) s += chs[(t0 + r * tpc) * 12 + which * 4 + q];
+    o[item] = s;
+  }
+}
+
+// grid = C/32 workgroups; 256 threads = 32 channels x 8 lanes over (b,g) pairs
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ sspart, const float* __restrict__ chpart,
+                                                              const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dbias, int B, int C, int G, int HW) {
+  extern __shared__ float sm[];  // [B][2] per-sample (s1/N, s2/N), then [8][32][3] reduce
+  float* ssb = sm;
+  float* redc = sm + 2 * B;
+  const float invN = 1.f / ((float)HW * (float)C);
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int g = 0; g < G; ++g) {
+      a1 += sspart[((size_t)b * G + g) * 2 + 0];
+      a2 += sspart[((size_t)b * G + g) * 2 + 1];
+    }
+    ssb[b * 2 + 0] = a1 * invN;
+    ssb[b * 2 + 1] = a2 * invN;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float dg = 0.f, dbt = 0.f, dbs = 0.f;
+  if (c < C) {
+    const float gm = gamma[c];
+    for (int b = bl; b < B; b += 8) {
+      float A = 0.f, Bc = 0.f, X = 0.f;
+      for (int g = 0; g < G; ++g) {
+        const float* o = chpart + ((size_t)b * G + g) * 3 * C;
+        A += o[c]; Bc += o[C + c]; X += o[2 * C + c];
+      }
+      dbt += A; dg += Bc;
+      dbs += stats[b * 2 + 1] * (gm * A - (float)HW * ssb[b * 2 + 0] - X * ssb[b * 2 + 1]);
+    }
+  }
+  redc[(bl * 32 + cl) * 3 + 0] = dg;
+  redc[(bl * 32 + cl) * 3 + 1] = dbt;
+  redc[(bl * 32 + cl) * 3 + 2] = dbs;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    for (int k = 0; k < 8; ++k) {
+      r0 += redc[(k * 32 + cl) * 3 + 0];
+      r1 += redc[(k * 32 + cl) * 3 + 1];
+      r2 += redc[(k * 32 + cl) * 3 + 2];
+    }
+    dgamma[c] = r0; dbeta[c] = r1;
+    if (dbias) dbias[c] = r2;
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ da,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ stats, const float* __restrict__ sspart,
+                                                           float* __restrict__ dy, long long N, int C, int G, int cpg) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, g = blockIdx.x;
+  const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
+  float a1 = 0.f, a2 = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) {
+    a1 += sspart[((size_t)b * G + i) * 2 + 0];
+    a2 += sspart[((size_t)b * G + i) * 2 + 1];
+  }
+  const float m1 = block_sum_256(a1, red) / (float)N;
+  const float m2 = block_sum_256(a2, red) / (float)N;
+  const float* yb = y + (size_t)b * N;
+  const float* db = da + (size_t)b * N;
+  float* ob = dy + (size_t)b * N;
+  const int ch = (threadIdx.x * 4) % C;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + ch);
+  const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + ch);
+  for (int c = 0; c < cpg; ++c) {
+    const long long base = ((long long)g * cpg + c) * LN_CHUNK;
+    if (base >= N) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = base + (threadIdx.x + 256 * j) * 4;
+      if (e < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(yb + e);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(db + e);
+        const f32x4 xh = (v - mean) * rstd;
+        const f32x4 n = xh * gm + bt;
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float dn = d[q] * (n[q] > 0.f ? 1.f : __expf(n[q]));
+          o[q] = rstd * (dn * gm[q] - m1 - xh[q] * m2);
+        }
+        *reinterpret_cast<f32x4*>(ob + e) = o;
+      }
+    }
+  }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------
+extern "C" size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C) {
+  const LnGeom g = ln_geom(B, HW, C);
+  // fwd: part[B][G][3]; bwd: sspart[B][G][2] + chpart[B][G][3][C]
+  return ((size_t)B * g.G * 3 + (size_t)B * g.G * 2 + (size_t)B * g.G * 3 * C) * sizeof(float) + 256;
+}
+
+static int ln_check(const char* name, int B, int HW, int C, size_t ws_bytes, void* ws) {
+  SGG_CHECK_ARG(B > 0 && HW > 0 && C >= 4, "%s: bad dims", name);
+  SGG_CHECK_ARG(C <= 1024 && (LN_CHUNK % C) == 0, "%s: C must be a power of two in [4, 1024] (got %d)", name, C);
+  if (!ws || ws_bytes < sgg_layernorm_hwc_elu_workspace_bytes(B, HW, C)) {
+    sgg_set_error("%s: workspace too small", name);
+    return SGG_ERR_WORKSPACE;
+  }
+  return SGG_OK;
+}
+
+extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats, int B,
+                                         int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+  SGG_CHECK_ARG(y && gamma && beta && a && stats, "sgg_layernorm_hwc_elu_fwd: null pointer");
+  int rc = ln_check("sgg_layernorm_hwc_elu_fwd", B, HW, C, ws_bytes, ws);
+  if (rc) return rc;
+  const LnGeom g = ln_geom(B, HW, C);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(ln_stats_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg);
+  hipLaunchKernelGGL(ln_apply_elu_kernel, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)part, a, stats, g.N,
+                     C, g.G, g.cpg);
+  SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_fwd");
+  return SGG_OK;
+}
+
+extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
+                                         const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev, int B,
+                                         int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+  SGG_CHECK_ARG(y && da && gamma && beta && stats && dy && dgamma && dbeta, "sgg_layernorm_hwc_elu_bwd: null pointer");
+  int rc = ln_check("sgg_layernorm_hwc_elu_bwd", B, HW, C, ws_bytes, ws);
+  if (rc) return rc;
+  const LnGeom g = ln_geom(B, HW, C);
+  hipStream_t st = (hipStream_t)stream;
+  float* sspart = (float*)ws + (size_t)B * g.G * 3;
+  float* chpart = sspart + (size_t)B * g.G * 2;
+  hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart, g.N, C,
+                     g.G, g.cpg);
+  const size_t sm = (size_t)(2 * B + 8 * 32 * 3) * sizeof(float);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(256), sm, st, (const float*)sspart,
+                     (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, HW);
+  hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, (const float*)sspart, dy,
+                     g.N, C, g.G, g.cpg);
+  SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd");
+  return SGG_OK;
+}

@@ -1,0 +1,65 @@
+// Common host/device helpers for libsgg_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define SGG_OK 0
+#define SGG_ERR_ARG (-1)
+#define SGG_ERR_LAUNCH (-2)
+#define SGG_ERR_WORKSPACE (-3)
+
+extern "C" void sgg_set_error(const char* fmt, ...);
+
+#define SGG_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      sgg_set_error(__VA_ARGS__);                \
+      return SGG_ERR_ARG;                        \
+    }                                            \
+  } while (0)
+
+#define SGG_LAUNCH_CHECK(name)                                                   \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      sgg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return SGG_ERR_LAUNCH;                                                     \
+    }                                                                            \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int sgg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// ---- wave (64 lanes) reductions through DPP/ds_swizzle-backed shuffles -------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS. All threads get the sum.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// XCD-aware bijective block remap (cdna_hip_programming.md T1): consecutive logical ids share an XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+#endif

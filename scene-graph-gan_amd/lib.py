@@ -1,0 +1,347 @@
+"""ctypes binding of libsgg_hip.so (include/sgg_hip.h) on torch device tensors.
+
+PyTorch is plumbing only here: it owns device memory and the stream; every arithmetic op of the hot path is a
+hand-written HIP kernel behind the C ABI.  There is NO fallback: if the shared object is missing, fails to
+load, or a tensor is not on a HIP device, the call raises.
+
+Tensor conventions used by the host orchestration (trunk.py / head.py / step.py):
+  * head tensors carry a leading "plane" dimension: [1, R, W] for plain fp32, [2, R, W] for dual numbers
+    (plane 0 = real part, plane 1 = dual part; see csrc/dual.h).  Column slices of such buffers are passed as
+    strided views; the binding extracts base pointers and the row stride (leading dimension).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgg_hip.so")
+
+_vp, _i, _f, _sz, _ll = c_void_p, c_int, c_float, c_size_t, c_longlong
+
+# name -> (restype, argtypes); must list every symbol declared in include/sgg_hip.h
+SIGNATURES = {
+    "sgg_version": (_i, []),
+    "sgg_last_error": (c_char_p, []),
+    "sgg_device_info": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "sgg_hwio_to_hwoi": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
+    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 9 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sgg_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sgg_gemm_skinny_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "sgg_gemm_skinny_dgrad": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "sgg_gemm_skinny_wgrad": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "sgg_attn_ctx_gemm_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgg_attn_ctx_gemm_dgrad": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sgg_attn_ctx_gemm_wgrad": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sgg_attn_step_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sgg_attn_step_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sgg_lnlstm_gates_fwd": (_i, [_vp] * 9 + [_i, _i, _vp]),
+    "sgg_lnlstm_gates_bwd": (_i, [_vp] * 7 + [_i] + [_vp] * 7 + [_i, _vp]),
+    "sgg_colsum": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "sgg_onehot": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sgg_interpolate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sgg_wgan_gp_loss_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sgg_wgan_gp_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "sgg_wgan_losses": (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp]),
+    "sgg_adam_tf_multi": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _vp]),
+    "sgg_argmax_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sgg_fill": (_i, [_vp, _ll, _f, _vp]),
+}
+
+_lib = None
+
+
+class SggError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """Load libsgg_hip.so and bind every declared symbol. Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SggError("libsgg_hip.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def same_pads(in_size: int, k: int, s: int):
+    """TF SAME padding (tf.layers.conv2d(padding="same"), generator_with_attention.py:29): (out, before, after)."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return out, total // 2, total - total // 2
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipKernels:
+    """Tensor-level wrapper of the C ABI. All tensors must be fp32 (int64 where stated) on one HIP device."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise SggError("no HIP device visible: the scene-graph-gan_amd product path has no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check(self, rc, name):
+        if rc != 0:
+            raise SggError("%s failed (%d): %s" % (name, rc, self.lib.sgg_last_error().decode()))
+
+    def _dev(self, *ts):
+        for t in ts:
+            if t is not None and (not t.is_cuda):
+                raise SggError("tensor is not on a HIP device (no CPU fallback in the product path)")
+
+    def workspace(self, nbytes: int):
+        if self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def device_info(self):
+        cu, lds, hbm = c_int(0), c_size_t(0), c_size_t(0)
+        arch = ctypes.create_string_buffer(64)
+        self._check(self.lib.sgg_device_info(ctypes.addressof(cu), ctypes.addressof(lds), ctypes.addressof(hbm),
+                                             ctypes.addressof(arch), 64), "sgg_device_info")
+        return {"cu_count": cu.value, "lds_bytes_per_cu": lds.value, "hbm_bytes": hbm.value, "arch": arch.value.decode()}
+
+    # -- conv encoder ----------------------------------------------------------------------------------
+    def hwio_to_hwoi(self, w, wt):
+        self._dev(w, wt)
+        kh, kw, ci, co = w.shape
+        self._check(self.lib.sgg_hwio_to_hwoi(_p(w), _p(wt), kh * kw, ci, co, self._stream()), "sgg_hwio_to_hwoi")
+
+    @staticmethod
+    def _conv_dims(x_shape, w_shape, stride):
+        B, Hi, Wi, Ci = x_shape
+        KH, KW, Ci2, Co = w_shape
+        assert Ci == Ci2
+        Ho, pt, _ = same_pads(Hi, KH, stride)
+        Wo, pl, _ = same_pads(Wi, KW, stride)
+        return B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pt, pl
+
+    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride):
+        """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
+        self._dev(x, w_fwd, bias, y)
+        d = self._conv_dims(x.shape, w_hwio.shape, stride)
+        assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
+        self._check(self.lib.sgg_conv2d_nhwc_fwd(_p(x), _p(w_fwd), _p(bias), _p(y), *d, self._stream()), "sgg_conv2d_nhwc_fwd")
+
+    def conv_dgrad(self, dy, w_hwio, dx, stride):
+        self._dev(dy, w_hwio, dx)
+        d = self._conv_dims(dx.shape, w_hwio.shape, stride)
+        assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
+        self._check(self.lib.sgg_conv2d_nhwc_dgrad(_p(dy), _p(w_hwio), _p(dx), *d, self._stream()), "sgg_conv2d_nhwc_dgrad")
+
+    def conv_wgrad(self, x, dy, dw, stride):
+        self._dev(x, dy, dw)
+        d = self._conv_dims(x.shape, dw.shape, stride)
+        assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous()
+        need = self.lib.sgg_conv2d_nhwc_wgrad_workspace_bytes(*d[:9])
+        ws = self.workspace(need)
+        self._check(self.lib.sgg_conv2d_nhwc_wgrad(_p(x), _p(dy), _p(dw), *d, _p(ws), ws.numel(), self._stream()),
+                    "sgg_conv2d_nhwc_wgrad")
+
+    def ln_elu_fwd(self, y, gamma, beta, a, stats):
+        self._dev(y, gamma, beta, a, stats)
+        B, H, W, C = y.shape
+        need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
+        ws = self.workspace(need)
+        self._check(self.lib.sgg_layernorm_hwc_elu_fwd(_p(y), _p(gamma), _p(beta), _p(a), _p(stats), B, H * W, C, _p(ws),
+                                                       ws.numel(), self._stream()), "sgg_layernorm_hwc_elu_fwd")
+
+    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev):
+        self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev)
+        B, H, W, C = y.shape
+        need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
+        ws = self.workspace(need)
+        self._check(self.lib.sgg_layernorm_hwc_elu_bwd(_p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma),
+                                                       _p(dbeta), _p(dbias_prev), B, H * W, C, _p(ws), ws.numel(),
+                                                       self._stream()), "sgg_layernorm_hwc_elu_bwd")
+
+    # -- heads -----------------------------------------------------------------------------------------
+    def spatial_mean_fwd(self, ctx, out_c, out_h):
+        """ctx [B,L,C]; out_c / out_h: [R,C] (strided) views; row r gets mean_l ctx[r % B]."""
+        self._dev(ctx, out_c, out_h)
+        B, L, C = ctx.shape
+        R = out_c.shape[0]
+        self._check(self.lib.sgg_spatial_mean_fwd(_p(ctx), _p(out_c), out_c.stride(0), _p(out_h), out_h.stride(0), R, B, L, C,
+                                                  self._stream()), "sgg_spatial_mean_fwd")
+
+    def spatial_mean_bwd(self, dc0, dh0, dctx, accumulate):
+        self._dev(dc0, dh0, dctx)
+        B, L, C = dctx.shape
+        R = dc0.shape[0]
+        self._check(self.lib.sgg_spatial_mean_bwd(_p(dc0), dc0.stride(0), _p(dh0), dh0.stride(0), _p(dctx), R, B, L, C,
+                                                  int(accumulate), self._stream()), "sgg_spatial_mean_bwd")
+
+    def _gemm(self, mode, M, N, K, A, Bm, C, bias, accumulate):
+        self._dev(A, Bm, C, bias)
+        assert A.stride(1) == 1 and Bm.stride(1) == 1 and C.stride(1) == 1
+        need = self.lib.sgg_gemm_workspace_bytes(M, N, K)
+        ws = self.workspace(need)
+        if mode == 0:
+            rc = self.lib.sgg_gemm_skinny_fwd(M, N, K, _p(A), A.stride(0), _p(Bm), Bm.stride(0), _p(C), C.stride(0), _p(bias),
+                                              int(accumulate), _p(ws), ws.numel(), self._stream())
+        else:
+            fn = self.lib.sgg_gemm_skinny_dgrad if mode == 1 else self.lib.sgg_gemm_skinny_wgrad
+            rc = fn(M, N, K, _p(A), A.stride(0), _p(Bm), Bm.stride(0), _p(C), C.stride(0), int(accumulate), _p(ws), ws.numel(),
+                    self._stream())
+        self._check(rc, ("sgg_gemm_skinny_fwd", "sgg_gemm_skinny_dgrad", "sgg_gemm_skinny_wgrad")[mode])
+
+    def gemm_nn(self, A, Bm, C, bias=None, accumulate=False):
+        """C[M,N] (+)= A[M,K] @ B[K,N] (+ bias)"""
+        M, K = A.shape
+        K2, N = Bm.shape
+        assert K == K2 and tuple(C.shape) == (M, N)
+        self._gemm(0, M, N, K, A, Bm, C, bias, accumulate)
+
+    def gemm_nt(self, A, Bm, C, accumulate=False):
+        """C[M,N] (+)= A[M,K] @ B[N,K]^T"""
+        M, K = A.shape
+        N, K2 = Bm.shape
+        assert K == K2 and tuple(C.shape) == (M, N)
+        self._gemm(1, M, N, K, A, Bm, C, None, accumulate)
+
+    def gemm_tn(self, A, Bm, C, accumulate=False):
+        """C[M,N] (+)= A[K,M]^T @ B[K,N]"""
+        K, M = A.shape
+        K2, N = Bm.shape
+        assert K == K2 and tuple(C.shape) == (M, N)
+        self._gemm(2, M, N, K, A, Bm, C, None, accumulate)
+
+    @staticmethod
+    def _planes(t):
+        """[np, R, W] (strided) -> (ptr_real, ptr_dual or None, ld)"""
+        if t is None:
+            return None, None, 0
+        assert t.dim() == 3 and t.stride(2) == 1
+        return t[0].data_ptr(), (t[1].data_ptr() if t.shape[0] == 2 else None), t.stride(1)
+
+    def attn_step_fwd(self, P, ec, ctx, alpha, z):
+        """P [B,L]; ec, alpha [np,R,L]; z [np,R,C] view; ctx [B,L,C]."""
+        self._dev(P, ec, ctx, alpha, z)
+        B, L, C = ctx.shape
+        R = ec.shape[1]
+        er, ed, lde = self._planes(ec)
+        ar, ad, lda = self._planes(alpha)
+        zr, zd, ldz = self._planes(z)
+        assert lda == L
+        self._check(self.lib.sgg_attn_step_fwd(_p(P), er, ed, lde, _p(ctx), ar, ad, zr, zd, ldz, R, B, L, C, self._stream()),
+                    "sgg_attn_step_fwd")
+
+    def attn_step_bwd(self, ctx, alpha, dz, de, dP, dctx, accumulate):
+        self._dev(ctx, alpha, dz, de, dP, dctx)
+        B, L, C = ctx.shape
+        R = alpha.shape[1]
+        ar, ad, lda = self._planes(alpha)
+        zr, zd, ldz = self._planes(dz)
+        er, ed, lde = self._planes(de)
+        assert lda == L and lde == L
+        self._check(self.lib.sgg_attn_step_bwd(_p(ctx), ar, ad, zr, zd, ldz, er, ed, _p(dP), _p(dctx), R, B, L, C, int(accumulate),
+                                               self._stream()), "sgg_attn_step_bwd")
+
+    def lstm_fwd(self, gates, c_prev, ln_params, c_new, h_new):
+        """gates [np,R,2048], c_prev/c_new [np,R,512] contiguous, h_new [np,R,512] view, ln_params [10,512]."""
+        self._dev(gates, c_prev, ln_params, c_new, h_new)
+        R = gates.shape[1]
+        gr, gd, ldg = self._planes(gates)
+        cr, cd, ldc = self._planes(c_prev)
+        nr, nd, ldn = self._planes(c_new)
+        hr, hd, ldh = self._planes(h_new)
+        assert ldg == 2048 and ldc == 512 and ldn == 512
+        self._check(self.lib.sgg_lnlstm_gates_fwd(gr, gd, cr, cd, _p(ln_params), nr, nd, hr, hd, ldh, R, self._stream()),
+                    "sgg_lnlstm_gates_fwd")
+
+    def lstm_bwd(self, gates, c_prev, ln_params, dh, dc_new, dgates, dc_prev, pgrad):
+        """dh [np,R,512] view; dc_new [np,R,512] or None; outputs dgates [np,R,2048], dc_prev [np,R,512], pgrad [R,10,512]."""
+        self._dev(gates, c_prev, ln_params, dh, dc_new, dgates, dc_prev, pgrad)
+        R = gates.shape[1]
+        gr, gd, ldg = self._planes(gates)
+        cr, cd, ldc = self._planes(c_prev)
+        hr, hd, ldh = self._planes(dh)
+        nr, nd, ldn = self._planes(dc_new)
+        dgr, dgd, lddg = self._planes(dgates)
+        dpr, dpd, lddp = self._planes(dc_prev)
+        assert ldg == 2048 and ldc == 512 and lddg == 2048 and lddp == 512 and (dc_new is None or ldn == 512)
+        self._check(self.lib.sgg_lnlstm_gates_bwd(gr, gd, cr, cd, _p(ln_params), hr, hd, ldh, nr, nd, dgr, dgd, dpr, dpd,
+                                                  _p(pgrad), R, self._stream()), "sgg_lnlstm_gates_bwd")
+
+    def colsum(self, X, out, accumulate=False):
+        self._dev(X, out)
+        rows, cols = X.shape
+        assert X.stride(1) == 1
+        self._check(self.lib.sgg_colsum(_p(X), rows, cols, X.stride(0), _p(out), int(accumulate), self._stream()), "sgg_colsum")
+
+    # -- loss / optimiser / misc -----------------------------------------------------------------------
+    def onehot(self, labels, out):
+        self._dev(labels, out)
+        assert labels.dtype == torch.int64
+        V = out.shape[-1]
+        self._check(self.lib.sgg_onehot(_p(labels), _p(out), labels.numel(), V, self._stream()), "sgg_onehot")
+
+    def interpolate(self, real, fake, alpha, out):
+        self._dev(real, fake, alpha, out)
+        B = real.shape[0]
+        self._check(self.lib.sgg_interpolate(_p(real), _p(fake), _p(alpha), _p(out), B, real.numel() // B, self._stream()),
+                    "sgg_interpolate")
+
+    def gp_fwd(self, g, slopes, pen):
+        self._dev(g, slopes, pen)
+        B = g.shape[0]
+        self._check(self.lib.sgg_wgan_gp_loss_fwd(_p(g), _p(slopes), _p(pen), B, g.numel() // B, self._stream()),
+                    "sgg_wgan_gp_loss_fwd")
+
+    def gp_bwd(self, g, slopes, pen, v, scale):
+        self._dev(g, slopes, pen, v)
+        B = g.shape[0]
+        self._check(self.lib.sgg_wgan_gp_loss_bwd(_p(g), _p(slopes), _p(pen), _p(v), B, g.numel() // B, float(scale),
+                                                  self._stream()), "sgg_wgan_gp_loss_bwd")
+
+    def wgan_losses(self, d_out, pen, lam, B, T, has_real, out4):
+        self._dev(d_out, pen, out4)
+        self._check(self.lib.sgg_wgan_losses(_p(d_out), _p(pen), float(lam), B, T, int(has_real), _p(out4), self._stream()),
+                    "sgg_wgan_losses")
+
+    def adam(self, params, grads, m, v, lr_t, b1, b2, eps, grad_scale=1.0):
+        self._dev(params, grads, m, v)
+        self._check(self.lib.sgg_adam_tf_multi(_p(params), _p(grads), _p(m), _p(v), params.numel(), float(lr_t), float(b1),
+                                               float(b2), float(eps), float(grad_scale), self._stream()), "sgg_adam_tf_multi")
+
+    def argmax_rows(self, x, out):
+        self._dev(x, out)
+        assert x.stride(-1) == 1 and out.dtype == torch.int64
+        V = x.shape[-1]
+        x2 = x.reshape(-1, V)
+        self._check(self.lib.sgg_argmax_rows(_p(x2), _p(out), x2.shape[0], V, x2.stride(0), self._stream()), "sgg_argmax_rows")
+
+    def fill(self, t, value):
+        self._dev(t)
+        assert t.is_contiguous()
+        self._check(self.lib.sgg_fill(_p(t), t.numel(), float(value), self._stream()), "sgg_fill")

@@ -1,0 +1,324 @@
+"""-m gpu: every HIP kernel, called through the C ABI (sgg_amd.lib.HipKernels), against the kernel-level CPU
+reference (oracle/kernels_ref.py, computed in fp64 on the same seeded inputs).
+
+Tolerance: fp32 arithmetic with different summation order than the reference ->
+|hip - ref| <= ATOL + RTOL * max|ref| with RTOL = 2e-5 (contractions of up to ~13k terms), stated per test.
+Integer outputs (argmax) are compared exactly.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import sgg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rnd(shape, seed, scale=1.0):
+    return (torch.randn(shape, generator=g(seed), dtype=torch.float32) * scale)
+
+
+def close(hip_t, ref_t, rtol=2e-5, atol=1e-6, what=""):
+    h = hip_t.detach().cpu().double()
+    r = ref_t.detach().cpu().double()
+    assert h.shape == r.shape, (what, h.shape, r.shape)
+    assert torch.isfinite(h).all(), what + ": non-finite values"
+    tol = atol + rtol * float(r.abs().max())
+    err = float((h - r).abs().max())
+    assert err <= tol, "%s: max err %.3e > tol %.3e (max|ref| %.3e)" % (what, err, tol, float(r.abs().max()))
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride
+    (2, 12, 12, 32, 32, 3, 1),
+    (2, 12, 10, 32, 64, 3, 1),
+    (1, 9, 9, 64, 128, 3, 1),
+    (2, 8, 8, 128, 256, 3, 1),
+    (1, 6, 6, 256, 512, 3, 1),
+    (2, 12, 12, 32, 32, 5, 2),      # even size: SAME pads (1,2)
+    (2, 13, 11, 32, 32, 5, 2),      # odd size: pads (2,2)
+    (2, 8, 8, 128, 128, 5, 2),
+    (1, 4, 4, 512, 512, 5, 2),
+    (3, 20, 20, 64, 64, 3, 1),      # M = 1200: several tiles + ragged last tile
+    (2, 10, 10, 3, 32, 3, 1),       # conv1_1 path (Cin = 3)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(hip, ref, case):
+    B, H, W, Ci, Co, k, s = case
+    x = rnd((B, H, W, Ci), 1)
+    w = rnd((k, k, Ci, Co), 2, 1.0 / math.sqrt(k * k * Ci))
+    b = rnd((Co,), 3, 0.1)
+    Ho, Wo = O.same_pads(H, k, s)[0], O.same_pads(W, k, s)[0]
+    dy = rnd((B, Ho, Wo, Co), 4)
+    # reference in fp64
+    xr, wr, br, dyr = x.double(), w.double(), b.double(), dy.double()
+    y_ref = torch.empty((B, Ho, Wo, Co), dtype=torch.float64)
+    ref.conv_fwd(xr, wr, None, br, y_ref, s)
+    dw_ref = torch.empty_like(wr)
+    ref.conv_wgrad(xr, dyr, dw_ref, s)
+    # hip
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    if Ci == 3:
+        wf = wd
+    else:
+        wf = torch.empty((k, k, Co, Ci), device="cuda")
+        hip.hwio_to_hwoi(wd, wf)
+        close(wf, w.permute(0, 1, 3, 2), 0, 0, "hwio_to_hwoi")
+    y = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
+    hip.conv_fwd(xd, wd, wf, bd, y, s)
+    close(y, y_ref, what="conv_fwd %s" % (case,))
+    dw = torch.full_like(wd, float("nan"))
+    hip.conv_wgrad(xd, dyd, dw, s)
+    close(dw, dw_ref, what="conv_wgrad %s" % (case,))
+    if Ci != 3:
+        dx_ref = torch.empty_like(xr)
+        ref.conv_dgrad(dyr, wr, dx_ref, s)
+        dx = torch.full_like(xd, float("nan"))
+        hip.conv_dgrad(dyd, wd, dx, s)
+        close(dx, dx_ref, what="conv_dgrad %s" % (case,))
+
+
+def test_conv_wgrad_split_k(hip, ref):
+    # enough pixels that the pixel range is split over several workgroups (nsplit > 1)
+    B, H, W, Ci, Co, k, s = 4, 48, 48, 32, 32, 3, 1
+    x, dy = rnd((B, H, W, Ci), 5), rnd((B, H, W, Co), 6)
+    dw_ref = torch.empty((k, k, Ci, Co), dtype=torch.float64)
+    ref.conv_wgrad(x.double(), dy.double(), dw_ref, s)
+    dw = torch.full((k, k, Ci, Co), float("nan"), device="cuda")
+    hip.conv_wgrad(dev(x), dev(dy), dw, s)
+    close(dw, dw_ref, rtol=5e-5, what="wgrad split-k")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (3, 7, 7, 64), (2, 16, 16, 512), (2, 40, 40, 32), (1, 4, 4, 256)])
+def test_layernorm_elu(hip, ref, shape):
+    B, H, W, C = shape
+    y = rnd(shape, 7, 2.0) + 0.3
+    gamma, beta = 1.0 + rnd((C,), 8, 0.2), rnd((C,), 9, 0.2)
+    da = rnd(shape, 10)
+    a_ref = torch.empty(shape, dtype=torch.float64)
+    st_ref = torch.empty((B, 2), dtype=torch.float64)
+    ref.ln_elu_fwd(y.double(), gamma.double(), beta.double(), a_ref, st_ref)
+    dy_ref = torch.empty(shape, dtype=torch.float64)
+    dg_ref, db_ref, dbias_ref = (torch.empty(C, dtype=torch.float64) for _ in range(3))
+    ref.ln_elu_bwd(y.double(), da.double(), gamma.double(), beta.double(), st_ref, dy_ref, dg_ref, db_ref, dbias_ref)
+    yd, gd, bd, dad = dev(y), dev(gamma), dev(beta), dev(da)
+    a = torch.full(shape, float("nan"), device="cuda")
+    st = torch.empty((B, 2), device="cuda")
+    hip.ln_elu_fwd(yd, gd, bd, a, st)
+    close(a, a_ref, what="ln fwd")
+    close(st, st_ref, what="ln stats")
+    dy = torch.full(shape, float("nan"), device="cuda")
+    dg, db, dbias = (torch.full((C,), float("nan"), device="cuda") for _ in range(3))
+    hip.ln_elu_bwd(yd, dad, gd, bd, st, dy, dg, db, dbias)
+    close(dy, dy_ref, rtol=5e-5, what="ln bwd dy")
+    close(dg, dg_ref, rtol=5e-5, what="ln dgamma")
+    close(db, db_ref, rtol=5e-5, what="ln dbeta")
+    close(dbias, dbias_ref, rtol=5e-5, atol=2e-5, what="ln dbias_prev")
+
+
+GEMM_CASES = [(8, 16, 8704), (64, 196, 4096), (24, 50, 512), (24, 2048, 562), (64, 300, 1000), (8, 1, 512),
+              (70, 130, 33), (192, 2048, 1324)]
+
+
+@pytest.mark.parametrize("mnk", GEMM_CASES)
+def test_gemm_modes(hip, ref, mnk):
+    M, N, K = mnk
+    A, Bm, bias = rnd((M, K), 11), rnd((K, N), 12), rnd((N,), 13)
+    C0 = rnd((M, N), 14)
+    # NN (+bias), also with accumulate
+    Cr = torch.empty((M, N), dtype=torch.float64)
+    ref.gemm_nn(A.double(), Bm.double(), Cr, bias.double())
+    C = torch.full((M, N), float("nan"), device="cuda")
+    hip.gemm_nn(dev(A), dev(Bm), C, dev(bias))
+    close(C, Cr, what="gemm_nn %s" % (mnk,))
+    C = dev(C0)
+    hip.gemm_nn(dev(A), dev(Bm), C, None, accumulate=True)
+    close(C, C0.double() + A.double() @ Bm.double(), what="gemm_nn acc %s" % (mnk,))
+    # NT
+    Bt = Bm.t().contiguous()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    hip.gemm_nt(dev(A), dev(Bt), C)
+    close(C, A.double() @ Bm.double(), what="gemm_nt %s" % (mnk,))
+    # TN
+    At = A.t().contiguous()
+    C = dev(C0)
+    hip.gemm_tn(dev(At), dev(Bm), C, accumulate=True)
+    close(C, C0.double() + A.double() @ Bm.double(), what="gemm_tn %s" % (mnk,))
+
+
+def test_gemm_strided_views(hip):
+    # column slices of wider buffers (leading dimension != width), as the heads use them
+    R, W0 = 24, 812 + 512
+    XH = dev(rnd((R, W0), 15))
+    K = dev(rnd((W0, 2048), 16, 0.05))
+    G = torch.empty((R, 2048), device="cuda")
+    hip.gemm_nn(XH, K, G)
+    close(G, XH.cpu().double() @ K.cpu().double(), what="gates gemm")
+    out = torch.zeros((R, 3, 50), device="cuda")
+    Wd = dev(rnd((512, 50), 17, 0.05))
+    bd = dev(rnd((50,), 18))
+    hip.gemm_nn(XH[:, 812:], Wd, out[:, 1, :], bd)
+    close(out[:, 1, :], XH[:, 812:].cpu().double() @ Wd.cpu().double() + bd.cpu().double(), what="decoder slab")
+    assert float(out[:, 0, :].abs().max()) == 0.0 and float(out[:, 2, :].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [(4, 1, 16), (4, 3, 16), (3, 2, 196), (2, 1, 784)])
+@pytest.mark.parametrize("dual", [False, True])
+def test_attention_step(hip, ref, cfg, dual):
+    B, npass, L = cfg
+    C, R, np_ = 512, B * npass, (2 if dual else 1)
+    P, ctx = rnd((B, L), 20), rnd((B, L, C), 21)
+    ec, dz = rnd((np_, R, L), 22), rnd((np_, R, C), 23)
+    al_ref = torch.empty((np_, R, L), dtype=torch.float64)
+    z_ref = torch.empty((np_, R, C), dtype=torch.float64)
+    ref.attn_step_fwd(P.double(), ec.double(), ctx.double(), al_ref, z_ref)
+    de_ref = torch.empty((np_, R, L), dtype=torch.float64)
+    dP0, dctx0 = rnd((B, L), 24), rnd((B, L, C), 25)
+    dP_ref, dctx_ref = dP0.double().clone(), dctx0.double().clone()
+    ref.attn_step_bwd(ctx.double(), al_ref, dz.double(), de_ref, dP_ref, dctx_ref, True)
+    Pd, ctxd, ecd, dzd = dev(P), dev(ctx), dev(ec), dev(dz)
+    al = torch.full((np_, R, L), float("nan"), device="cuda")
+    zbuf = torch.full((np_, R, C + 40), float("nan"), device="cuda")     # z lands in a column slice
+    hip.attn_step_fwd(Pd, ecd, ctxd, al, zbuf[:, :, :C])
+    close(al, al_ref, what="alpha")
+    close(zbuf[:, :, :C], z_ref, what="z")
+    de = torch.full((np_, R, L), float("nan"), device="cuda")
+    dP, dctx = dev(dP0), dev(dctx0)
+    hip.attn_step_bwd(ctxd, dev(al_ref.float()), dzd, de, dP, dctx, True)
+    close(de, de_ref, rtol=5e-5, what="de")
+    close(dP, dP_ref, rtol=5e-5, what="dP")
+    close(dctx, dctx_ref, rtol=5e-5, what="dctx")
+    # overwrite mode
+    dP2, dctx2 = torch.full_like(dP, float("nan")), torch.full_like(dctx, float("nan"))
+    hip.attn_step_bwd(ctxd, dev(al_ref.float()), dzd, de, dP2, dctx2, False)
+    close(dP2, dP_ref - dP0.double(), rtol=5e-5, atol=1e-5, what="dP overwrite")
+    close(dctx2, dctx_ref - dctx0.double(), rtol=5e-5, atol=1e-5, what="dctx overwrite")
+
+
+@pytest.mark.parametrize("R", [1, 6, 64])
+@pytest.mark.parametrize("dual", [False, True])
+def test_lnlstm_gates(hip, ref, R, dual):
+    np_ = 2 if dual else 1
+    gates, c_prev = rnd((np_, R, 2048), 30, 1.5), rnd((np_, R, 512), 31)
+    ln = torch.stack([1.0 + rnd((512,), 32 + i, 0.2) if i % 2 == 0 else rnd((512,), 32 + i, 0.2) for i in range(10)])
+    dh, dcn = rnd((np_, R, 512), 50), rnd((np_, R, 512), 51)
+    cn_ref, h_ref = (torch.empty((np_, R, 512), dtype=torch.float64) for _ in range(2))
+    ref.lstm_fwd(gates.double(), c_prev.double(), ln.double(), cn_ref, h_ref)
+    dg_ref = torch.empty((np_, R, 2048), dtype=torch.float64)
+    dcp_ref = torch.empty((np_, R, 512), dtype=torch.float64)
+    pg_ref = torch.empty((R, 10, 512), dtype=torch.float64)
+    ref.lstm_bwd(gates.double(), c_prev.double(), ln.double(), dh.double(), dcn.double(), dg_ref, dcp_ref, pg_ref)
+    gd, cd, lnd, dhd, dcnd = dev(gates), dev(c_prev), dev(ln), dev(dh), dev(dcn)
+    cn = torch.full((np_, R, 512), float("nan"), device="cuda")
+    hbuf = torch.full((np_, R, 812 + 512), float("nan"), device="cuda")
+    hip.lstm_fwd(gd, cd, lnd, cn, hbuf[:, :, 812:])
+    close(cn, cn_ref, what="c_new")
+    close(hbuf[:, :, 812:], h_ref, what="h_new")
+    dg = torch.full((np_, R, 2048), float("nan"), device="cuda")
+    dcp = torch.full((np_, R, 512), float("nan"), device="cuda")
+    pg = torch.full((R, 10, 512), float("nan"), device="cuda")
+    hip.lstm_bwd(gd, cd, lnd, dhd, dcnd, dg, dcp, pg)
+    close(dg, dg_ref, rtol=1e-4, what="dgates")
+    close(dcp, dcp_ref, rtol=1e-4, what="dc_prev")
+    close(pg, pg_ref, rtol=1e-4, what="pgrad")
+    # no cotangent on the new cell state
+    ref.lstm_bwd(gates.double(), c_prev.double(), ln.double(), dh.double(), None, dg_ref, dcp_ref, pg_ref)
+    hip.lstm_bwd(gd, cd, lnd, dhd, None, dg, dcp, pg)
+    close(dg, dg_ref, rtol=1e-4, what="dgates (dc_new=None)")
+
+
+def test_spatial_mean_colsum(hip, ref):
+    B, L, C, npass = 3, 16, 512, 2
+    R = B * npass
+    ctx = rnd((B, L, C), 60)
+    oc = torch.full((R, C), float("nan"), device="cuda")
+    ohb = torch.full((R, 300 + C), float("nan"), device="cuda")
+    hip.spatial_mean_fwd(dev(ctx), oc, ohb[:, 300:])
+    m = ctx.double().mean(dim=1).repeat(npass, 1)
+    close(oc, m, what="c0")
+    close(ohb[:, 300:], m, what="h0")
+    dc0, dh0, dctx0 = rnd((R, C), 61), rnd((R, C), 62), rnd((B, L, C), 63)
+    dref = dctx0.double().clone()
+    ref.spatial_mean_bwd(dc0.double(), dh0.double(), dref, True)
+    d = dev(dctx0)
+    hip.spatial_mean_bwd(dev(dc0), dev(dh0), d, True)
+    close(d, dref, what="spatial_mean_bwd")
+    X = rnd((37, 5120), 64)
+    out = dev(rnd((5120,), 65))
+    exp = out.cpu().double() + X.double().sum(0)
+    hip.colsum(dev(X), out, True)
+    close(out, exp, what="colsum")
+
+
+def test_loss_adam_argmax(hip, ref):
+    B, T, V = 8, 3, 50
+    labels = torch.randint(0, V, (B, T), generator=g(70))
+    oh = torch.empty((B, T, V), device="cuda")
+    hip.onehot(labels.cuda(), oh)
+    assert torch.equal(oh.cpu(), torch.nn.functional.one_hot(labels, V).float())
+    fake, alpha = rnd((B, T, V), 71), torch.rand((B,), generator=g(72))
+    xh = torch.empty((B, T, V), device="cuda")
+    hip.interpolate(oh, dev(fake), dev(alpha), xh)
+    close(xh, oh.cpu().double() + alpha.double()[:, None, None] * (fake.double() - oh.cpu().double()), what="interpolate")
+    gr = rnd((B, T, V), 73, 0.2)
+    gr[0] *= 0.01   # a row with slope < 1 (one-sided penalty inactive)
+    sl, pen = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    hip.gp_fwd(dev(gr), sl, pen)
+    slr, penr = torch.empty(B, dtype=torch.float64), torch.empty(B, dtype=torch.float64)
+    ref.gp_fwd(gr.double(), slr, penr)
+    close(sl, slr, what="slopes"); close(pen, penr, what="pen")
+    assert float(pen[0]) == 0.0
+    v = torch.empty((B, T, V), device="cuda")
+    hip.gp_bwd(dev(gr), sl, pen, v, 10.0)
+    vr = torch.empty((B, T, V), dtype=torch.float64)
+    ref.gp_bwd(gr.double(), slr, penr, vr, 10.0)
+    close(v, vr, what="gp_bwd")
+    d_out = rnd((3 * B, T), 74)
+    out4 = torch.empty(4, device="cuda")
+    hip.wgan_losses(dev(d_out), pen, 10.0, B, T, True, out4)
+    o4 = torch.empty(4, dtype=torch.float64)
+    ref.wgan_losses(d_out.double(), penr, 10.0, B, T, True, o4)
+    close(out4, o4, what="wgan_losses")
+    # TF Adam, 3 steps, odd length (tail path)
+    n = 4099
+    p, gg = rnd((n,), 75), rnd((n,), 76, 0.1)
+    pr, mr, vr_ = p.double().clone(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    buf = torch.zeros((4, 4112), device="cuda")
+    pd, gd, md, vd = buf[0, :n], buf[1, :n], buf[2, :n], buf[3, :n]
+    pd.copy_(p); gd.copy_(gg)
+    for t in range(1, 4):
+        lr_t = O.tf_adam_lr_t(t)
+        hip.adam(pd, gd, md, vd, lr_t, O.ADAM_B1, O.ADAM_B2, O.ADAM_EPS)
+        ref.adam(pr, gg.double(), mr, vr_, lr_t, O.ADAM_B1, O.ADAM_B2, O.ADAM_EPS)
+    close(pd, pr, rtol=1e-6, what="adam params")
+    close(md, mr, rtol=1e-5, what="adam m")
+    # argmax with ties: first index wins
+    x = rnd((B * T, V), 77)
+    x[0, 7] = x[0, 31] = 100.0
+    x[1, :] = 0.0
+    out = torch.empty(B * T, dtype=torch.int64, device="cuda")
+    hip.argmax_rows(dev(x), out)
+    assert torch.equal(out.cpu(), O.argmax_tokens(x))
+    assert int(out[0]) == 7 and int(out[1]) == 0
+
+
+def test_errors_are_loud(hip):
+    from sgg_amd.lib import SggError
+    x = torch.zeros((1, 4, 4, 24), device="cuda")       # Cin not a multiple of 32
+    w = torch.zeros((3, 3, 24, 32), device="cuda")
+    y = torch.zeros((1, 4, 4, 32), device="cuda")
+    with pytest.raises(SggError):
+        hip.conv_fwd(x, w, w, torch.zeros(32, device="cuda"), y, 1)
+    with pytest.raises(SggError):
+        hip.fill(torch.zeros(4), 1.0)                    # CPU tensor: no fallback
