@@ -94,6 +94,11 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _ld(t):
+    """row stride of a 2-D view whose last dim is contiguous (torch reports arbitrary strides for size-1 dims)"""
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
 class HipKernels:
     """Tensor-level wrapper of the C ABI. All tensors must be fp32 (int64 where stated) on one HIP device."""
 
@@ -191,14 +196,14 @@ class HipKernels:
         self._dev(ctx, out_c, out_h)
         B, L, C = ctx.shape
         R = out_c.shape[0]
-        self._check(self.lib.sgg_spatial_mean_fwd(_p(ctx), _p(out_c), out_c.stride(0), _p(out_h), out_h.stride(0), R, B, L, C,
+        self._check(self.lib.sgg_spatial_mean_fwd(_p(ctx), _p(out_c), _ld(out_c), _p(out_h), _ld(out_h), R, B, L, C,
                                                   self._stream()), "sgg_spatial_mean_fwd")
 
     def spatial_mean_bwd(self, dc0, dh0, dctx, accumulate):
         self._dev(dc0, dh0, dctx)
         B, L, C = dctx.shape
         R = dc0.shape[0]
-        self._check(self.lib.sgg_spatial_mean_bwd(_p(dc0), dc0.stride(0), _p(dh0), dh0.stride(0), _p(dctx), R, B, L, C,
+        self._check(self.lib.sgg_spatial_mean_bwd(_p(dc0), _ld(dc0), _p(dh0), _ld(dh0), _p(dctx), R, B, L, C,
                                                   int(accumulate), self._stream()), "sgg_spatial_mean_bwd")
 
     def _gemm(self, mode, M, N, K, A, Bm, C, bias, accumulate):
@@ -207,11 +212,11 @@ class HipKernels:
         need = self.lib.sgg_gemm_workspace_bytes(M, N, K)
         ws = self.workspace(need)
         if mode == 0:
-            rc = self.lib.sgg_gemm_skinny_fwd(M, N, K, _p(A), A.stride(0), _p(Bm), Bm.stride(0), _p(C), C.stride(0), _p(bias),
+            rc = self.lib.sgg_gemm_skinny_fwd(M, N, K, _p(A), _ld(A), _p(Bm), _ld(Bm), _p(C), _ld(C), _p(bias),
                                               int(accumulate), _p(ws), ws.numel(), self._stream())
         else:
             fn = self.lib.sgg_gemm_skinny_dgrad if mode == 1 else self.lib.sgg_gemm_skinny_wgrad
-            rc = fn(M, N, K, _p(A), A.stride(0), _p(Bm), Bm.stride(0), _p(C), C.stride(0), int(accumulate), _p(ws), ws.numel(),
+            rc = fn(M, N, K, _p(A), _ld(A), _p(Bm), _ld(Bm), _p(C), _ld(C), int(accumulate), _p(ws), ws.numel(),
                     self._stream())
         self._check(rc, ("sgg_gemm_skinny_fwd", "sgg_gemm_skinny_dgrad", "sgg_gemm_skinny_wgrad")[mode])
 
@@ -242,7 +247,8 @@ class HipKernels:
         if t is None:
             return None, None, 0
         assert t.dim() == 3 and t.stride(2) == 1
-        return t[0].data_ptr(), (t[1].data_ptr() if t.shape[0] == 2 else None), t.stride(1)
+        ld = t.stride(1) if t.shape[1] > 1 else max(t.stride(1), t.shape[2])
+        return t[0].data_ptr(), (t[1].data_ptr() if t.shape[0] == 2 else None), ld
 
     def attn_step_fwd(self, P, ec, ctx, alpha, z):
         """P [B,L]; ec, alpha [np,R,L]; z [np,R,C] view; ctx [B,L,C]."""
@@ -297,7 +303,7 @@ class HipKernels:
         self._dev(X, out)
         rows, cols = X.shape
         assert X.stride(1) == 1
-        self._check(self.lib.sgg_colsum(_p(X), rows, cols, X.stride(0), _p(out), int(accumulate), self._stream()), "sgg_colsum")
+        self._check(self.lib.sgg_colsum(_p(X), rows, cols, _ld(X), _p(out), int(accumulate), self._stream()), "sgg_colsum")
 
     # -- loss / optimiser / misc -----------------------------------------------------------------------
     def onehot(self, labels, out):
@@ -339,7 +345,7 @@ class HipKernels:
         assert x.stride(-1) == 1 and out.dtype == torch.int64
         V = x.shape[-1]
         x2 = x.reshape(-1, V)
-        self._check(self.lib.sgg_argmax_rows(_p(x2), _p(out), x2.shape[0], V, x2.stride(0), self._stream()), "sgg_argmax_rows")
+        self._check(self.lib.sgg_argmax_rows(_p(x2), _p(out), x2.shape[0], V, _ld(x2), self._stream()), "sgg_argmax_rows")
 
     def fill(self, t, value):
         self._dev(t)
