@@ -1,0 +1,178 @@
+"""Attention + LayerNorm-LSTM head of both networks: forward, hand-scheduled backward, and their dual-number
+evaluation for the gradient-penalty term.
+
+Reference: architectures/generator_with_attention.py:13-18, 74-91 (generator head),
+architectures/discriminator_with_attention.py:13-18, 73-93 (critic head); gradients as produced by
+optimizer.minimize / tfgan's gradient penalty (train.py:245-250, 265-266).
+
+Design notes (MI355X-first, not a translation of the TF graph):
+  * the step-invariant product ctx_flat @ W_ctx (+ bias) of the attention perceptron is computed once per
+    forward (`precompute`), the reference graph rebuilds it four times (generator_with_attention.py:81,86);
+  * the critic's fake / real / interpolated passes share one feature map, so they run as ONE super-batch of
+    R = 3B rows through every GEMM (weights stream once), row r using image r % B;
+  * concat([z_hat, u_t, h]) is never materialised: the attention kernel, the embedding GEMM and the gate kernel
+    write straight into column ranges of one [R, in+512] buffer that feeds the gate GEMM;
+  * tensors carry a leading plane dimension np: 1 = fp32, 2 = dual numbers (real, dual) - the same schedule
+    then computes the JVP / second-order backward of the gradient penalty (csrc/dual.h).
+"""
+from __future__ import annotations
+
+import torch
+
+from .params import FEAT_C, LSTM_LN_SCOPES, NUM_UNITS, T_STEPS
+
+C = FEAT_C
+H = NUM_UNITS
+
+
+def flat2(t):
+    """[np, R, w] view whose planes are R rows apart -> [np*R, w] (stacked rows for one GEMM)."""
+    np_, R, w = t.shape
+    if np_ == 1:
+        return t[0]
+    assert t.stride(0) == R * t.stride(1) and t.stride(2) == 1
+    return t.as_strided((np_ * R, w), (t.stride(1), 1), t.storage_offset())
+
+
+class HeadState:
+    """Activation / cotangent buffers of one head pass with R rows and np planes."""
+
+    def __init__(self, head, np_, R):
+        dev, dt = head.device, head.dtype
+        z = lambda *s: torch.zeros(s, device=dev, dtype=dt)
+        self.np, self.R = np_, R
+        W, L, Vout = head.width, head.L, head.Vout
+        self.C = [z(np_, R, H) for _ in range(T_STEPS + 1)]
+        self.XH = [z(np_, R, W) for _ in range(T_STEPS + 1)]
+        self.EC = [z(np_, R, L) for _ in range(T_STEPS)]
+        self.AL = [z(np_, R, L) for _ in range(T_STEPS)]
+        self.G = [z(np_, R, 4 * H) for _ in range(T_STEPS)]
+        self.OUT = z(np_, R, T_STEPS, Vout)
+        self.dOUT = z(np_, R, T_STEPS, Vout)
+        self.dXH = [z(np_, R, W) for _ in range(T_STEPS + 1)]
+        self.dC = [z(np_, R, H) for _ in range(T_STEPS + 1)]
+        self.dG = z(np_, R, 4 * H)
+        self.dE = z(np_, R, L)
+        self.pgrad = z(T_STEPS * R, 10, H)
+
+
+class Head:
+    def __init__(self, K, kind, arena, grad_views, B, L):
+        self.K, self.kind, self.B, self.L = K, kind, B, L
+        self.device, self.dtype = arena.flat.device, arena.flat.dtype
+        p, g = arena.views, grad_views
+        self.V, self.E = arena.V, arena.E
+        self.in_dim = C + (H if kind == "G" else self.E)
+        self.width = self.in_dim + H
+        self.Vout = self.V if kind == "G" else 1
+        LC = L * C
+        self.W_ctx, self.W_c = p["attention_perceptron/kernel"][:LC], p["attention_perceptron/kernel"][LC:]
+        self.gW_ctx, self.gW_c = g["attention_perceptron/kernel"][:LC], g["attention_perceptron/kernel"][LC:]
+        self.b_att, self.gb_att = p["attention_perceptron/bias"], g["attention_perceptron/bias"]
+        self.Kk, self.gKk = p["layer_norm_basic_lstm_cell/kernel"], g["layer_norm_basic_lstm_cell/kernel"]
+        first = "layer_norm_basic_lstm_cell/%s/gamma" % LSTM_LN_SCOPES[0]
+        o = arena.offsets[first]
+        # the ten LN vectors (gamma, beta of input, transform, forget, output, state) are contiguous in the arena
+        self.ln = arena.flat[o:o + 10 * H].view(10, H)
+        gflat = g[first]
+        self.gln = gflat.as_strided((10 * H,), (1,), gflat.storage_offset())
+        assert self.ln[2].data_ptr() == p["layer_norm_basic_lstm_cell/transform/gamma"].data_ptr()
+        assert self.ln[9].data_ptr() == p["layer_norm_basic_lstm_cell/state/beta"].data_ptr()
+        self.W_dec, self.gW_dec = p["decoder/kernel"], g["decoder/kernel"]
+        self.b_dec, self.gb_dec = p["decoder/bias"], g["decoder/bias"]
+        if kind == "D":
+            self.W_emb, self.gW_emb = p["W"], g["W"]
+        z = lambda *s: torch.zeros(s, device=self.device, dtype=self.dtype)
+        self.P = z(B, L)
+        self.dP = z(B, L)
+        self.dctx = z(B, L, C)
+        self._trashP, self._trashCtx = z(B, L), z(B, L, C)
+        self._states = {}
+
+    def state(self, np_, R, tag=""):
+        key = (np_, R, tag)
+        if key not in self._states:
+            self._states[key] = HeadState(self, np_, R)
+        return self._states[key]
+
+    # ------------------------------------------------------------------------------------------------
+    def precompute(self, ctx):
+        """P = ctx_flat @ W_ctx + b_att, once per feature map; also clears the dP / dctx accumulators."""
+        K = self.K
+        K.gemm_nn(ctx.view(self.B, self.L * C), self.W_ctx, self.P, self.b_att)
+        K.fill(self.dP, 0.0)
+        K.fill(self.dctx, 0.0)
+
+    def forward(self, st, ctx, u):
+        """u: generator: noise [R, 512] (reused at t = 0,1,2, generator_with_attention.py:81,86);
+        critic: list over planes of triples [R, 3, V] (float one-hot / logits / tangent direction).
+        Fills st.OUT [np, R, 3, Vout]."""
+        K, np_, R, ind = self.K, st.np, st.R, self.in_dim
+        K.spatial_mean_fwd(ctx, st.C[0][0], st.XH[0][0][:, ind:])       # plane 1 (tangent of c0 = h0) stays zero
+        for t in range(T_STEPS):
+            K.gemm_nn(flat2(st.C[t]), self.W_c, flat2(st.EC[t]))
+            K.attn_step_fwd(self.P, st.EC[t], ctx, st.AL[t], st.XH[t][:, :, :C])
+            if self.kind == "G":
+                st.XH[t][0][:, C:ind].copy_(u)
+            else:
+                for pl in range(np_):
+                    K.gemm_nn(u[pl][:, t, :], self.W_emb, st.XH[t][pl][:, C:ind])
+            K.gemm_nn(flat2(st.XH[t]), self.Kk, flat2(st.G[t]))
+            K.lstm_fwd(st.G[t], st.C[t], self.ln, st.C[t + 1], st.XH[t + 1][:, :, ind:])
+            K.gemm_nn(st.XH[t + 1][0][:, ind:], self.W_dec, st.OUT[0][:, t, :], self.b_dec)
+            if np_ == 2:
+                K.gemm_nn(st.XH[t + 1][1][:, ind:], self.W_dec, st.OUT[1][:, t, :])
+        return st.OUT
+
+    # ------------------------------------------------------------------------------------------------
+    def _wgrad(self, X, dY, dW, R_w):
+        """dW += pcot(X^T dY) over the first R_w rows. X, dY: [np, R, *] tensors or per-plane lists."""
+        if R_w == 0:
+            return
+        K = self.K
+        if len(X) == 1:
+            K.gemm_tn(X[0][:R_w], dY[0][:R_w], dW, accumulate=True)
+        else:
+            K.gemm_tn(X[0][:R_w], dY[1][:R_w], dW, accumulate=True)
+            K.gemm_tn(X[1][:R_w], dY[0][:R_w], dW, accumulate=True)
+
+    def backward(self, st, ctx, u, R_w):
+        """Backward of `forward` from st.dOUT. Rows [0, R_w) contribute to parameter / dP / dctx gradients (all
+        accumulated); every row gets its data cotangents (st.dXH[t][:, :, 512:in] = cotangent of u_t)."""
+        K, np_, R, ind = self.K, st.np, st.R, self.in_dim
+        pc = np_ - 1                                    # plane holding cotangents of real quantities
+        assert R_w % self.B == 0 and (np_ == 1 or R_w == R)
+        for t in range(T_STEPS - 1, -1, -1):
+            dout = st.dOUT[:, :, t, :]
+            dh = st.dXH[t + 1][:, :, ind:]
+            for pl in range(np_):
+                K.gemm_nt(dout[pl], self.W_dec, dh[pl], accumulate=(t < T_STEPS - 1))
+            if R_w:
+                self._wgrad(st.XH[t + 1][:, :, ind:], dout, self.gW_dec, R_w)
+                K.colsum(dout[pc][:R_w], self.gb_dec, True)
+            K.lstm_bwd(st.G[t], st.C[t], self.ln, dh, st.dC[t + 1] if t < T_STEPS - 1 else None, st.dG, st.dC[t],
+                       st.pgrad[t * R:(t + 1) * R])
+            self._wgrad(st.XH[t], st.dG, self.gKk, R_w)
+            K.gemm_nt(flat2(st.dG), self.Kk, flat2(st.dXH[t]))
+            if self.kind == "D" and R_w:
+                self._wgrad([x[:, t, :] for x in u], st.dXH[t][:, :, C:ind], self.gW_emb, R_w)
+            dz = st.dXH[t][:, :, :C]
+            if R_w:
+                K.attn_step_bwd(ctx, st.AL[t][:, :R_w], dz[:, :R_w], st.dE[:, :R_w], self.dP, self.dctx, True)
+            if R_w < R:
+                K.attn_step_bwd(ctx, st.AL[t][:, R_w:], dz[:, R_w:], st.dE[:, R_w:], self._trashP, self._trashCtx, False)
+            self._wgrad(st.C[t], st.dE, self.gW_c, R_w)
+            K.gemm_nt(flat2(st.dE), self.W_c, flat2(st.dC[t]), accumulate=True)
+        if R_w:
+            K.spatial_mean_bwd(st.dC[0][pc][:R_w], st.dXH[0][pc][:R_w, ind:], self.dctx, True)
+            for t in range(T_STEPS):
+                K.colsum(st.pgrad[t * R:t * R + R_w].view(R_w, 10 * H), self.gln, True)
+
+    def finish_backward(self, ctx):
+        """Gradients that flow through the step-invariant score P (after every head pass of the step)."""
+        K, B, L = self.K, self.B, self.L
+        ctx_flat = ctx.view(B, L * C)
+        K.colsum(self.dP, self.gb_att, True)
+        K.gemm_tn(ctx_flat, self.dP, self.gW_ctx, accumulate=True)
+        K.gemm_nt(self.dP, self.W_ctx, self.dctx.view(B, L * C), accumulate=True)
+        return self.dctx

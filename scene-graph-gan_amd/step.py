@@ -1,0 +1,160 @@
+"""WGAN-GP critic step and generator step (one "G+D step" = critic_iters critic updates + one generator update).
+
+Reference: train.py:239-266 (tfgan gan_model / gan_loss with wasserstein losses + one-sided gradient penalty,
+two Adam optimisers, variable partition by name prefix) and the loop body train.py:362-368.
+
+Critic step:   G forward (fake logits, constant for D) -> D encoder forward ONCE (fake / real / interpolated share
+               the images) -> critic head on the 3B-row super-batch -> first-order backward (parameter gradients
+               from the fake and real rows; g = d sum(D(x_hat)) / d x_hat from the interpolated rows) -> penalty
+               and v = lambda * dGP/dg -> dual-number head pass on the interpolated rows (JVP along v, then the same
+               backward evaluated on duals = gradient of the penalty) -> encoder backward -> [all-reduce] -> TF-Adam.
+Generator step: G forward -> D forward with the updated critic -> backward through the critic head to the fake
+               logits -> generator head + encoder backward -> [all-reduce] -> TF-Adam.
+No autograd tape is used anywhere in this path; every arithmetic op is a HIP kernel behind the C ABI.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .head import Head
+from .params import ADAM_B1, ADAM_B2, ADAM_EPS, ADAM_LR, EMBED_DIM, FEAT_C, NUM_UNITS, T_STEPS, ParamArena
+from .trunk import Trunk
+
+
+def tf_adam_lr_t(t, lr=ADAM_LR, b1=ADAM_B1, b2=ADAM_B2):
+    """tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)."""
+    return lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+
+
+class Network:
+    """Parameters (+ gradient / Adam arenas), encoder and head of one network."""
+
+    def __init__(self, K, kind, V, S, B, E=EMBED_DIM, device=None, dtype=torch.float32, state_dict=None):
+        self.K, self.kind = K, kind
+        device = device if device is not None else K.device
+        self.arena = ParamArena(kind, V, S, E, device=device, dtype=dtype)
+        if state_dict is not None:
+            self.arena.load_state_dict(state_dict)
+        self.grad_flat, self.grads = self.arena.like()
+        self.m_flat, _ = self.arena.like()
+        self.v_flat, _ = self.arena.like()
+        self.adam_t = 0
+        self.trunk = Trunk(K, self.arena, self.grads, B, S)
+        self.head = Head(K, kind, self.arena, self.grads, B, self.trunk.L)
+
+    def zero_grads(self):
+        self.K.fill(self.arena.live(self.grad_flat), 0.0)
+
+    def adam_step(self, grad_scale=1.0):
+        self.adam_t += 1
+        a = self.arena
+        self.K.adam(a.live(), a.live(self.grad_flat), a.live(self.m_flat), a.live(self.v_flat),
+                    tf_adam_lr_t(self.adam_t), ADAM_B1, ADAM_B2, ADAM_EPS, grad_scale)
+        self.trunk.refresh_weights()
+
+
+class GanStep:
+    """The training hot path for a fixed (B, S, V). `reducer(network)` (optional) all-reduces network.grad_flat
+    across data-parallel ranks and returns the scale to apply to the gradient (1/world_size)."""
+
+    def __init__(self, K, V, S, B, lam=10.0, E=EMBED_DIM, g_state=None, d_state=None, dtype=torch.float32, reducer=None):
+        self.K, self.V, self.S, self.B, self.lam = K, V, S, B, float(lam)
+        self.G = Network(K, "G", V, S, B, E, dtype=dtype, state_dict=g_state)
+        self.D = Network(K, "D", V, S, B, E, dtype=dtype, state_dict=d_state)
+        self.reducer = reducer
+        dev = self.G.arena.flat.device
+        z = lambda *s: torch.zeros(s, device=dev, dtype=dtype)
+        self.TRI = z(3 * B, T_STEPS, V)          # rows: fake | real (one-hot) | interpolated
+        self.gbuf = z(B, T_STEPS, V)             # g = d sum(D(x_hat)) / d x_hat
+        self.vbuf = z(B, T_STEPS, V)             # lambda * dGP/dg
+        self.slopes, self.pen = z(B), z(B)
+        self.dfake = z(1, B, T_STEPS, V)
+        self.d_losses, self.g_losses = z(4), z(4)
+        self.tokens = torch.zeros((B, T_STEPS), dtype=torch.int64, device=dev)
+
+    # ------------------------------------------------------------------------------------------------
+    def generator_forward(self, images, noise):
+        """Generator.build_generator: fake logits [B,3,V] (a view of the critic's input slab)."""
+        G = self.G
+        ctx = G.trunk.forward(images)
+        G.head.precompute(ctx)
+        st = G.head.state(1, self.B)
+        G.head.forward(st, ctx, noise)
+        return st, ctx
+
+    def critic_step(self, images, labels, noise, alpha):
+        """One disc_train_op (train.py:365). labels int64 [B,3]; noise [B,512]; alpha [B]. Returns self.d_losses
+        = (disc_cost, wasserstein term, gradient penalty, mean D(fake)) as a device tensor."""
+        K, B, V, D = self.K, self.B, self.V, self.D
+        fake_rows, real_rows, hat_rows = self.TRI[:B], self.TRI[B:2 * B], self.TRI[2 * B:]
+        gst, _ = self.generator_forward(images, noise)
+        fake_rows.copy_(gst.OUT[0])
+        K.onehot(labels, real_rows)
+        K.interpolate(real_rows, fake_rows, alpha, hat_rows)
+        D.zero_grads()
+        ctx = D.trunk.forward(images)
+        D.head.precompute(ctx)
+        # ---- first-order pass on the 3B-row super-batch ------------------------------------------------
+        st = D.head.state(1, 3 * B)
+        D.head.forward(st, ctx, [self.TRI])
+        inv = 1.0 / (B * T_STEPS)
+        K.fill(st.dOUT[0][:B], inv)               # d mean(D(fake))
+        K.fill(st.dOUT[0][B:2 * B], -inv)         # d -mean(D(real))
+        K.fill(st.dOUT[0][2 * B:], 1.0)           # d sum(D(x_hat)) -> g
+        D.head.backward(st, ctx, [self.TRI], R_w=2 * B)
+        ind = D.head.in_dim
+        for t in range(T_STEPS):
+            K.gemm_nt(st.dXH[t][0][2 * B:, FEAT_C:ind], D.head.W_emb, self.gbuf[:, t, :])
+        K.gp_fwd(self.gbuf, self.slopes, self.pen)
+        K.gp_bwd(self.gbuf, self.slopes, self.pen, self.vbuf, self.lam)
+        K.wgan_losses(st.OUT[0].view(3 * B, T_STEPS), self.pen, self.lam, B, T_STEPS, True, self.d_losses)
+        # ---- gradient of lambda*GP: dual-number pass on the interpolated rows ------------------------------
+        st2 = D.head.state(2, B)
+        u2 = [hat_rows, self.vbuf]
+        D.head.forward(st2, ctx, u2)
+        K.fill(st2.dOUT[0], 1.0)                  # cotangent of the tangent output (= d(lambda*GP)/d JVP)
+        K.fill(st2.dOUT[1], 0.0)
+        D.head.backward(st2, ctx, u2, R_w=B)
+        # W enters g = delta_e @ W^T directly as well: handled by the tangent input v @ W above (u2[1])
+        dctx = D.head.finish_backward(ctx)
+        D.trunk.backward(dctx)
+        scale = self.reducer(D) if self.reducer is not None else 1.0
+        D.adam_step(scale)
+        return self.d_losses
+
+    def generator_step(self, images, noise):
+        """One gen_train_op (train.py:368). Returns self.g_losses; g_losses[3] = mean D(fake) = -gen_cost."""
+        K, B, G, D = self.K, self.B, self.G, self.D
+        G.zero_grads()
+        gst, gctx = self.generator_forward(images, noise)
+        fake = gst.OUT[0]
+        ctx = D.trunk.forward(images)
+        D.head.precompute(ctx)
+        st = D.head.state(1, B, "g")
+        D.head.forward(st, ctx, [fake])
+        K.wgan_losses(st.OUT[0].view(B, T_STEPS), None, 0.0, B, T_STEPS, False, self.g_losses)
+        K.fill(st.dOUT[0], -1.0 / (B * T_STEPS))  # gen_cost = -mean(D(G(x)))
+        D.head.backward(st, ctx, [fake], R_w=0)
+        ind = D.head.in_dim
+        for t in range(T_STEPS):
+            K.gemm_nt(st.dXH[t][0][:, FEAT_C:ind], D.head.W_emb, gst.dOUT[0][:, t, :])
+        G.head.backward(gst, gctx, None, R_w=B)
+        dctx = G.head.finish_backward(gctx)
+        G.trunk.backward(dctx)
+        scale = self.reducer(G) if self.reducer is not None else 1.0
+        G.adam_step(scale)
+        return self.g_losses
+
+    def train_iteration(self, images, labels, noises, alphas, critic_iters=1):
+        """Loop body of train.py:362-368: critic_iters critic updates then one generator update on one minibatch,
+        fresh noise / alpha per update."""
+        for i in range(critic_iters):
+            self.critic_step(images, labels, noises[i], alphas[i])
+        self.generator_step(images, noises[critic_iters])
+
+    def argmax_tokens(self, logits):
+        """tf.argmax(fake_inputs, -1) (train.py:270)."""
+        self.K.argmax_rows(logits, self.tokens.view(-1))
+        return self.tokens

@@ -1,0 +1,95 @@
+"""Convolutional encoder (12 live conv layers, 11 of them followed by LayerNorm(H,W,C)+ELU): forward and the
+hand-scheduled backward over the HIP kernels.
+
+Reference: architectures/generator_with_attention.py:29-68 == architectures/discriminator_with_attention.py:29-68
+(forward); gradients as produced by optimizer.minimize (train.py:265-266).  conv3_3/conv3_4 and their
+LayerNorms (:59-62) never reach `downsampled` and are neither computed nor given gradients.
+
+HBM layout: per layer the conv output y_i and the activation a_i = ELU(LN(y_i)) stay resident for the backward
+pass (5.6 GB per network at batch 64 / 224x224 - sized for 288 GB of HBM3E, nothing is recomputed); the
+backward pass ping-pongs two scratch tensors (dA, dY) of the largest activation size.
+"""
+from __future__ import annotations
+
+import torch
+
+from .params import CONV_SPECS, FEAT_C, conv_name, ln_name, same_pads
+
+
+class Trunk:
+    def __init__(self, K, arena, grad_views, B, S):
+        self.K, self.B, self.S = K, B, S
+        dev, dt = arena.flat.device, arena.flat.dtype
+        p, g = arena.views, grad_views
+        self.layers = []
+        h = w = S
+        cin_shape = (B, S, S, 3)
+        max_act = 0
+        for (i, cin, cout, k, s, has_ln, live) in CONV_SPECS:
+            if not live:
+                continue
+            ho, wo = same_pads(h, k, s)[0], same_pads(w, k, s)[0]
+            lay = {
+                "i": i, "cin": cin, "cout": cout, "k": k, "s": s, "has_ln": has_ln,
+                "in_shape": cin_shape, "out_shape": (B, ho, wo, cout),
+                "w": p[conv_name(i) + "/kernel"], "b": p[conv_name(i) + "/bias"],
+                "gw": g[conv_name(i) + "/kernel"], "gb": g[conv_name(i) + "/bias"],
+                "y": torch.empty((B, ho, wo, cout), device=dev, dtype=dt),
+            }
+            lay["w_fwd"] = lay["w"] if cin == 3 else torch.empty((k, k, cout, cin), device=dev, dtype=dt)
+            if has_ln:
+                lay["gamma"], lay["beta"] = p[ln_name(i) + "/gamma"], p[ln_name(i) + "/beta"]
+                lay["ggamma"], lay["gbeta"] = g[ln_name(i) + "/gamma"], g[ln_name(i) + "/beta"]
+                lay["a"] = torch.empty((B, ho, wo, cout), device=dev, dtype=dt)
+                lay["stats"] = torch.empty((B, 2), device=dev, dtype=dt)
+                max_act = max(max_act, B * ho * wo * cout)
+            self.layers.append(lay)
+            h, w, cin_shape = ho, wo, (B, ho, wo, cout)
+        self.Hf, self.Wf = h, w
+        self.L = h * w
+        self._dA = torch.empty(max_act, device=dev, dtype=dt)
+        self._dY = torch.empty(max_act, device=dev, dtype=dt)
+        self.refresh_weights()
+
+    def refresh_weights(self):
+        """Re-derive the HWOI forward layout after the parameters changed (Adam step / state-dict load)."""
+        for lay in self.layers:
+            if lay["cin"] != 3:
+                self.K.hwio_to_hwoi(lay["w"], lay["w_fwd"])
+
+    def forward(self, images):
+        """images [B,S,S,3] NHWC fp32, already standardised (train.py:172) -> downsampled as ctx [B, L, 512]."""
+        assert tuple(images.shape) == (self.B, self.S, self.S, 3), images.shape
+        K = self.K
+        self.images = images
+        x = images
+        for lay in self.layers:
+            K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
+            if lay["has_ln"]:
+                K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"])
+                x = lay["a"]
+            else:
+                x = lay["y"]
+        return x.view(self.B, self.L, FEAT_C)
+
+    def backward(self, dctx):
+        """dctx [B, L, 512]: gradient w.r.t. `downsampled`. Writes every live conv / LN parameter gradient."""
+        K, B = self.K, self.B
+        dy = dctx.view(B, self.Hf, self.Wf, FEAT_C)
+        n = len(self.layers)
+        for j in range(n - 1, -1, -1):
+            lay = self.layers[j]
+            x_in = self.images if j == 0 else self.layers[j - 1]["a"]
+            K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
+            if not lay["has_ln"]:
+                # last conv: BiasAddGrad = column sums of dy (LN layers get theirs from ln_elu_bwd below)
+                K.colsum(dy.view(-1, lay["cout"]), lay["gb"], False)
+            if j == 0:
+                break
+            prev = self.layers[j - 1]
+            numel = prev["a"].numel()
+            dA = self._dA[:numel].view(prev["out_shape"])
+            dYp = self._dY[:numel].view(prev["out_shape"])
+            K.conv_dgrad(dy, lay["w"], dA, lay["s"])
+            K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"])
+            dy = dYp

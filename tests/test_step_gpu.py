@@ -1,0 +1,61 @@
+"""-m gpu: the full critic step + generator step on the MI355X (HIP kernels through the C ABI) against the CPU
+oracle on identical seeded inputs (BASELINE.json configs[0]: 8 x 64x64 images, vocab 50).
+
+Tolerances (fp32 on both sides, different summation orders):
+  losses / logits / critic outputs: |d| <= 1e-4 + 1e-4*|ref|
+  gradients and post-Adam weights : max|d| <= 1e-3 * max|ref| per tensor (+ floor 1e-7)
+  arg-maxed triple tokens         : exact, with the minimum top-2 logit margin reported
+"""
+import pytest
+import torch
+
+import sgg_amd  # noqa: F401
+from oracle import sgg_oracle as O
+from sgg_amd.step import GanStep
+
+pytestmark = pytest.mark.gpu
+
+
+def tensor_err(a, b):
+    return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-7))
+
+
+@pytest.mark.parametrize("scale_emb", [1.0, 25.0])      # 25: slopes > 1, gradient penalty (second-order path) active
+def test_gd_step_matches_oracle_config1(hip, scale_emb):
+    B, S, V = 8, 64, 50
+    gp, dp = O.init_params("G", V, S, perturb=0.05), O.init_params("D", V, S, perturb=0.05)
+    dp["W"] = dp["W"] * scale_emb
+    images, labels, onehot = O.synth_batch(B, S, V)
+    noise0, noise1, alpha = O.synth_noise(B, 0), O.synth_noise(B, 1), O.synth_alpha(B, 0)
+    gs = GanStep(hip, V, S, B, lam=10.0, g_state=gp, d_state=dp)
+
+    # forward parity of the generator alone
+    st, _ = gs.generator_forward(images.cuda(), noise0.cuda())
+    ref_logits = O.generator_forward(gp, images, noise0)
+    assert float((st.OUT[0].cpu() - ref_logits).abs().max()) <= 1e-4 + 1e-4 * float(ref_logits.abs().max())
+
+    d_adam, g_adam = O.new_adam_state(dp), O.new_adam_state(gp)
+    cost, aux, dgrads = O.d_step(gp, dp, d_adam, 1, images, onehot, noise0, alpha)
+    if scale_emb > 1:
+        assert float(aux["gp"]) > 1e-3
+    dl = gs.critic_step(images.cuda(), labels.cuda(), noise0.cuda(), alpha.reshape(B).cuda()).cpu()
+    assert abs(float(dl[0]) - float(cost)) <= 1e-4 + 1e-4 * abs(float(cost)), (dl, cost)
+    assert abs(float(dl[2]) - float(aux["gp"])) <= 1e-4 + 1e-3 * abs(float(aux["gp"])), (dl, aux["gp"])
+    worst = max((tensor_err(gs.D.grads[n], g), n) for n, g in dgrads.items())
+    assert worst[0] < 1e-3, "critic gradient %s: rel err %.3e" % (worst[1], worst[0])
+    worst = max((tensor_err(gs.D.arena.views[n], dp[n]), n) for n in dp if not O.is_dead(n))
+    assert worst[0] < 1e-3, "critic weights after Adam %s: rel err %.3e" % (worst[1], worst[0])
+
+    gcost, gaux, ggrads = O.g_step(gp, dp, g_adam, 1, images, noise1)
+    gl = gs.generator_step(images.cuda(), noise1.cuda()).cpu()
+    assert abs(-float(gl[3]) - float(gcost)) <= 1e-4 + 1e-4 * abs(float(gcost))
+    worst = max((tensor_err(gs.G.grads[n], g), n) for n, g in ggrads.items())
+    assert worst[0] < 1e-3, "generator gradient %s: rel err %.3e" % (worst[1], worst[0])
+    worst = max((tensor_err(gs.G.arena.views[n], gp[n]), n) for n in gp if not O.is_dead(n))
+    assert worst[0] < 1e-3, "generator weights after Adam %s: rel err %.3e" % (worst[1], worst[0])
+
+    toks = gs.argmax_tokens(gs.G.head.state(1, B).OUT[0]).cpu()
+    margin = O.top2_margin(gaux["fake"])
+    print("min top-2 logit margin: %.3e" % margin)
+    assert margin > 1e-4, "seed gives an argmax margin inside the fp tolerance"
+    assert torch.equal(toks, O.argmax_tokens(gaux["fake"]))
