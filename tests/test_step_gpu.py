@@ -20,6 +20,22 @@ def tensor_err(a, b):
     return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-7))
 
 
+def check_weights_after_adam(views, ref_params, ref_grads, old_params, t, what):
+    """First-step Adam is sign-like: update = lr_t*g/(|g|*c + eps'), so an element whose gradient is at the fp32
+    rounding-noise level may legitimately move by +-lr_t in either implementation.  Assert (a) every element
+    moved by at most the Adam bound, (b) elements with a significant gradient (>= 1% of the tensor's max) got
+    the oracle's update within 1% of lr_t."""
+    lr_t = O.tf_adam_lr_t(t)
+    bound = 1.05 * lr_t * (1 - O.ADAM_B1) / (1 - O.ADAM_B2) ** 0.5
+    for n, g in ref_grads.items():
+        w_hip, w_ref, w_old = views[n].cpu(), ref_params[n], old_params[n]
+        assert float((w_hip - w_old).abs().max()) <= bound, "%s %s: update exceeds the Adam bound" % (what, n)
+        sig = g.abs() >= 1e-2 * g.abs().max()
+        if sig.any():
+            d = ((w_hip - w_old) - (w_ref - w_old))[sig].abs().max()
+            assert float(d) <= 1e-2 * lr_t, "%s %s: update differs by %.3e (lr_t %.3e)" % (what, n, float(d), lr_t)
+
+
 @pytest.mark.parametrize("scale_emb", [1.0, 25.0])      # 25: slopes > 1, gradient penalty (second-order path) active
 def test_gd_step_matches_oracle_config1(hip, scale_emb):
     B, S, V = 8, 64, 50
@@ -28,6 +44,7 @@ def test_gd_step_matches_oracle_config1(hip, scale_emb):
     images, labels, onehot = O.synth_batch(B, S, V)
     noise0, noise1, alpha = O.synth_noise(B, 0), O.synth_noise(B, 1), O.synth_alpha(B, 0)
     gs = GanStep(hip, V, S, B, lam=10.0, g_state=gp, d_state=dp)
+    gp0, dp0 = {k: v.clone() for k, v in gp.items()}, {k: v.clone() for k, v in dp.items()}
 
     # forward parity of the generator alone
     st, _ = gs.generator_forward(images.cuda(), noise0.cuda())
@@ -41,18 +58,23 @@ def test_gd_step_matches_oracle_config1(hip, scale_emb):
     dl = gs.critic_step(images.cuda(), labels.cuda(), noise0.cuda(), alpha.reshape(B).cuda()).cpu()
     assert abs(float(dl[0]) - float(cost)) <= 1e-4 + 1e-4 * abs(float(cost)), (dl, cost)
     assert abs(float(dl[2]) - float(aux["gp"])) <= 1e-4 + 1e-3 * abs(float(aux["gp"])), (dl, aux["gp"])
-    worst = max((tensor_err(gs.D.grads[n], g), n) for n, g in dgrads.items())
+    # the critic's decoder bias gradient cancels analytically (+1 from the fake rows, -1 from the real rows, 0 from GP)
+    assert float(gs.D.grads["decoder/bias"].abs().max()) < 1e-5 and float(dgrads["decoder/bias"].abs().max()) < 1e-5
+    worst = max((tensor_err(gs.D.grads[n], g), n) for n, g in dgrads.items() if n != "decoder/bias")
     assert worst[0] < 1e-3, "critic gradient %s: rel err %.3e" % (worst[1], worst[0])
-    worst = max((tensor_err(gs.D.arena.views[n], dp[n]), n) for n in dp if not O.is_dead(n))
-    assert worst[0] < 1e-3, "critic weights after Adam %s: rel err %.3e" % (worst[1], worst[0])
+    check_weights_after_adam(gs.D.arena.views, dp, {n: g for n, g in dgrads.items() if n != "decoder/bias"}, dp0, 1, "critic")
 
+    # compare the generator step on IDENTICAL critic weights: the first Adam step moves noise-level gradient
+    # elements by +-lr in either implementation (see check_weights_after_adam), which would otherwise leak
+    # ~1e-4 of critic-output difference into this comparison.
+    gs.D.arena.load_state_dict(dp)
+    gs.D.trunk.refresh_weights()
     gcost, gaux, ggrads = O.g_step(gp, dp, g_adam, 1, images, noise1)
     gl = gs.generator_step(images.cuda(), noise1.cuda()).cpu()
     assert abs(-float(gl[3]) - float(gcost)) <= 1e-4 + 1e-4 * abs(float(gcost))
     worst = max((tensor_err(gs.G.grads[n], g), n) for n, g in ggrads.items())
     assert worst[0] < 1e-3, "generator gradient %s: rel err %.3e" % (worst[1], worst[0])
-    worst = max((tensor_err(gs.G.arena.views[n], gp[n]), n) for n in gp if not O.is_dead(n))
-    assert worst[0] < 1e-3, "generator weights after Adam %s: rel err %.3e" % (worst[1], worst[0])
+    check_weights_after_adam(gs.G.arena.views, gp, ggrads, gp0, 1, "generator")
 
     toks = gs.argmax_tokens(gs.G.head.state(1, B).OUT[0]).cpu()
     margin = O.top2_margin(gaux["fake"])
