@@ -110,6 +110,25 @@ class HipKernels:
             raise SggError("no HIP device visible: the scene-graph-gan_amd product path has no CPU fallback")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self.timing = None      # bench.py sets this to a list: conv launches are then bracketed by HIP events
+
+    def _timed(self, symbol, flops, fn):
+        """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline leg)."""
+        if self.timing is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        r = fn()
+        e1.record(torch.cuda.current_stream(self.device))
+        self.timing.append((symbol, flops, e0, e1))
+        return r
+
+    @staticmethod
+    def gather_symbol(n_out):
+        """Kernel symbol the implicit-GEMM dispatcher (csrc/conv_gather.hip: dispatch_gather) picks for N outputs."""
+        if n_out % 128 == 0:
+            return "conv_gather_kernel<128,128,2,2>"
+        return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather_kernel<256,32,4,1>"
 
     # -- plumbing ------------------------------------------------------------------------------------
     def _stream(self):
@@ -156,13 +175,18 @@ class HipKernels:
         self._dev(x, w_fwd, bias, y)
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
-        self._check(self.lib.sgg_conv2d_nhwc_fwd(_p(x), _p(w_fwd), _p(bias), _p(y), *d, self._stream()), "sgg_conv2d_nhwc_fwd")
+        flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
+        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else self.gather_symbol(d[6])
+        self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
+            _p(x), _p(w_fwd), _p(bias), _p(y), *d, self._stream())), "sgg_conv2d_nhwc_fwd")
 
     def conv_dgrad(self, dy, w_hwio, dx, stride):
         self._dev(dy, w_hwio, dx)
         d = self._conv_dims(dx.shape, w_hwio.shape, stride)
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
-        self._check(self.lib.sgg_conv2d_nhwc_dgrad(_p(dy), _p(w_hwio), _p(dx), *d, self._stream()), "sgg_conv2d_nhwc_dgrad")
+        flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
+        self._check(self._timed(self.gather_symbol(d[3]), flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
+            _p(dy), _p(w_hwio), _p(dx), *d, self._stream())), "sgg_conv2d_nhwc_dgrad")
 
     def conv_wgrad(self, x, dy, dw, stride):
         self._dev(x, dy, dw)
@@ -170,8 +194,9 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous()
         need = self.lib.sgg_conv2d_nhwc_wgrad_workspace_bytes(*d[:9])
         ws = self.workspace(need)
-        self._check(self.lib.sgg_conv2d_nhwc_wgrad(_p(x), _p(dy), _p(dw), *d, _p(ws), ws.numel(), self._stream()),
-                    "sgg_conv2d_nhwc_wgrad")
+        flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
+        self._check(self._timed("conv_wgrad(call: wgrad kernel + slab reduce)", flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
+            _p(x), _p(dy), _p(dw), *d, _p(ws), ws.numel(), self._stream())), "sgg_conv2d_nhwc_wgrad")
 
     def ln_elu_fwd(self, y, gamma, beta, a, stats):
         self._dev(y, gamma, beta, a, stats)

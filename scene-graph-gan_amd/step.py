@@ -41,11 +41,27 @@ class Network:
         self.m_flat, _ = self.arena.like()
         self.v_flat, _ = self.arena.like()
         self.adam_t = 0
+        self.pending = None          # in-flight gradient all-reduce (dp.PendingReduce) whose Adam step is deferred
         self.trunk = Trunk(K, self.arena, self.grads, B, S)
         self.head = Head(K, kind, self.arena, self.grads, B, self.trunk.L)
 
     def zero_grads(self):
+        assert self.pending is None
         self.K.fill(self.arena.live(self.grad_flat), 0.0)
+
+    def update(self, reducer):
+        """Gradients are complete: start their all-reduce (if data parallel) and defer the Adam step until the
+        weights are next needed (finish_update), so the collective overlaps with the other network's encoder."""
+        if reducer is None:
+            self.adam_step(1.0)
+        else:
+            self.pending = reducer(self)
+
+    def finish_update(self):
+        if self.pending is not None:
+            scale = self.pending.wait()
+            self.pending = None
+            self.adam_step(scale)
 
     def adam_step(self, grad_scale=1.0):
         self.adam_t += 1
@@ -89,13 +105,15 @@ class GanStep:
         = (disc_cost, wasserstein term, gradient penalty, mean D(fake)) as a device tensor."""
         K, B, V, D = self.K, self.B, self.V, self.D
         fake_rows, real_rows, hat_rows = self.TRI[:B], self.TRI[B:2 * B], self.TRI[2 * B:]
+        D.finish_update()
+        D.zero_grads()
+        ctx = D.trunk.forward(images)             # independent of G's weights: overlaps a pending G all-reduce
+        D.head.precompute(ctx)
+        self.G.finish_update()
         gst, _ = self.generator_forward(images, noise)
         fake_rows.copy_(gst.OUT[0])
         K.onehot(labels, real_rows)
         K.interpolate(real_rows, fake_rows, alpha, hat_rows)
-        D.zero_grads()
-        ctx = D.trunk.forward(images)
-        D.head.precompute(ctx)
         # ---- first-order pass on the 3B-row super-batch ------------------------------------------------
         st = D.head.state(1, 3 * B)
         D.head.forward(st, ctx, [self.TRI])
@@ -120,16 +138,17 @@ class GanStep:
         # W enters g = delta_e @ W^T directly as well: handled by the tangent input v @ W above (u2[1])
         dctx = D.head.finish_backward(ctx)
         D.trunk.backward(dctx)
-        scale = self.reducer(D) if self.reducer is not None else 1.0
-        D.adam_step(scale)
+        D.update(self.reducer)
         return self.d_losses
 
     def generator_step(self, images, noise):
         """One gen_train_op (train.py:368). Returns self.g_losses; g_losses[3] = mean D(fake) = -gen_cost."""
         K, B, G, D = self.K, self.B, self.G, self.D
+        G.finish_update()
         G.zero_grads()
-        gst, gctx = self.generator_forward(images, noise)
+        gst, gctx = self.generator_forward(images, noise)    # independent of D's weights: overlaps a pending D all-reduce
         fake = gst.OUT[0]
+        D.finish_update()
         ctx = D.trunk.forward(images)
         D.head.precompute(ctx)
         st = D.head.state(1, B, "g")
@@ -143,9 +162,13 @@ class GanStep:
         G.head.backward(gst, gctx, None, R_w=B)
         dctx = G.head.finish_backward(gctx)
         G.trunk.backward(dctx)
-        scale = self.reducer(G) if self.reducer is not None else 1.0
-        G.adam_step(scale)
+        G.update(self.reducer)
         return self.g_losses
+
+    def flush(self):
+        """Apply any deferred optimiser update (before reading weights / at the end of the timed region)."""
+        self.D.finish_update()
+        self.G.finish_update()
 
     def train_iteration(self, images, labels, noises, alphas, critic_iters=1):
         """Loop body of train.py:362-368: critic_iters critic updates then one generator update on one minibatch,
