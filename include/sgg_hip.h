@@ -106,7 +106,9 @@ int sgg_lnlstm_gates_bwd(const float* gates, const float* gates_dual, const floa
                          const float* ln_params, const float* dh, const float* dh_dual, int lddh, const float* dc_new,
                          const float* dc_new_dual, float* dgates, float* dgates_dual, float* dc_prev,
                          float* dc_prev_dual, float* pgrad, int R, void* stream);
-int sgg_colsum(const float* X, int rows, int cols, int ld, float* out, int accumulate, void* stream);
+size_t sgg_colsum_workspace_bytes(int rows, int cols);
+int sgg_colsum(const float* X, int rows, int cols, int ld, float* out, int accumulate, void* workspace,
+               size_t workspace_bytes, void* stream);
 
 /* ---- WGAN-GP loss: tf.contrib.gan.gan_loss(wasserstein_*, gradient_penalty_weight, one_sided) ---------------
  * train.py:245-250 */

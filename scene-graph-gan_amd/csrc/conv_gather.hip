@@ -14,6 +14,7 @@
 // staged global -> registers -> LDS (KC layout, see mma_f32.h) with the next slab's global loads in flight
 // while the current slab is contracted (register prefetch, one LDS buffer).
 #include "mma_f32.h"
+#include <stdlib.h>
 
 struct GatherClass {
   int Hm, Wm, M;        // virtual grid and B*Hm*Wm
@@ -34,6 +35,7 @@ struct GatherParams {
   int Ho, Wo;        // full output grid
   int sy, sx, dy, dx, osy, osx, KW;
   int ncls;
+  unsigned w_bytes;    // size of the weight tensor (bounds the buffer descriptor of the v2 kernel)
   GatherClass cls[4];
 };
 
@@ -159,6 +161,149 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// v3 of the same contraction for the MFMA-bound layers (N % 128 == 0 and C % 64 == 0): 64-deep slabs, so each
+// wave issues 128 MFMAs (8192 pipe cycles) per pair of barriers instead of 64, and a branch-free fetch.
+//   * measured on v1 (rocprofv3 PMC, conv2_4 forward): MFMA pipe busy 75 % at 2.14 GHz; per wave and slab 4096
+//     cycles of own MFMA, ~1000 of instruction issue (half of it address arithmetic with integer division) and
+//     ~1300 parked at s_waitcnt / s_barrier -> halve the barriers per MFMA and shrink the fetch;
+//   * gather through raw buffer loads (SRSRC descriptor): out-of-image taps, rows past M and slabs past the last
+//     get an out-of-range offset and the hardware returns zeros (TF SAME padding, no branches, no traffic);
+//   * the (tap, channel-block) walk is scalar counters; the slab fetch is one straight-line block issued right
+//     after the second barrier and in flight during the whole MFMA burst (register prefetch, one LDS buffer of
+//     (128+128) x 68 floats = 69.6 KB -> two workgroups per CU).
+// ---------------------------------------------------------------------------------------------------
+#define SGG_OOB 0x80000000u
+#define SGG_LDK64 68
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK>
+__global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_gather3_kernel(GatherParams p, unsigned src_bytes) {
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int CPR = BK / 4;                 // float4 pieces per tile row
+  constexpr int RPP = 256 / CPR;              // tile rows covered by one pass of the 256 threads
+  constexpr int LDKK = BK + 4;
+  constexpr int NPA = BM / RPP, NPB = BN / RPP;
+  static_assert(WGM * WGN == 4 && BM % RPP == 0 && BN % RPP == 0 && (BK == 32 || BK == 64), "tile");
+
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDKK + BM];
+  float* A_s = lds;
+  float* B_s = lds + BM * LDKK;
+  int* out_off_s = reinterpret_cast<int*>(lds + (BM + BN) * LDKK);
+
+  const GatherClass& c = p.cls[blockIdx.y];
+  const int ntiles_n = p.N / BN;
+  const int nwg = c.mtiles * ntiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int mt = lid / ntiles_n, nt = lid % ntiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int col4 = tid % CPR, prow = tid / CPR;
+
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wm), 0, p.w_bytes, 0x00020000);
+
+  int a_ys[NPA], a_xs[NPA], a_off[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int m = m0 + prow + RPP * j;
+    if (m < c.M) {
+      const int x = m % c.Wm;
+      const int t = m / c.Wm;
+      const int y = t % c.Hm;
+      const int b = t / c.Hm;
+      a_ys[j] = y * p.sy + c.oy;
+      a_xs[j] = x * p.sx + c.ox;
+      a_off[j] = ((b * p.Hs + a_ys[j]) * p.Ws + a_xs[j]) * p.C + col4 * 4;
+    } else {
+      a_ys[j] = -(1 << 28);
+      a_xs[j] = 0;
+      a_off[j] = 0;
+    }
+  }
+  const int b_off0 = (n0 + prow) * p.C + col4 * 4;      // row j adds RPP*j*C
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < c.M) {
+      const int x = m % c.Wm;
+      const int t = m / c.Wm;
+      const int y = t % c.Hm;
+      const int b = t / c.Hm;
+      off = ((b * p.Ho + y * p.osy + c.ooy) * p.Wo + x * p.osx + c.oox) * p.N;
+    }
+    out_off_s[r] = off;
+  }
+
+  f32x16 acc[TM][TN];
+  acc_zero<TM, TN>(acc);
+
+  const int n_iters = c.nth * c.ntw * (p.C / BK);
+  int s_th = 0, s_tw = 0, s_c0 = 0, s_it = 0;      // scalar walk over (th, tw, c0)
+  f32x4 ra[NPA], rb[NPB];
+  auto issue_loads = [&]() {
+    const unsigned dead = (unsigned)(s_it >= n_iters);   // past the last slab: all offsets out of range -> zeros
+    const int ty = s_th * p.dy, tx = s_tw * p.dx;
+    const int tapoff = (ty * p.Ws + tx) * p.C + s_c0;
+    const int woff = ((c.kh0 + c.kstep * s_th) * p.KW + (c.kw0 + c.kstep * s_tw)) * p.N * p.C + s_c0 + b_off0;
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int yy = a_ys[j] + ty, xx = a_xs[j] + tx;
+      // bitwise (not short-circuit) so the whole slab fetch stays one straight-line block
+      const unsigned bad = (unsigned)((unsigned)yy >= (unsigned)p.Hs) | (unsigned)((unsigned)xx >= (unsigned)p.Ws) | dead;
+      ra[j] = buf_load4(rs_src, ((unsigned)(a_off[j] + tapoff) * 4u) | ((0u - bad) & SGG_OOB));
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j)
+      rb[j] = buf_load4(rs_w, ((unsigned)(woff + RPP * j * p.C) * 4u) | ((0u - dead) & SGG_OOB));
+    ++s_it;
+    s_c0 += BK;
+    const bool wrap_c = s_c0 >= p.C;
+    s_c0 = wrap_c ? 0 : s_c0;
+    s_tw += wrap_c ? 1 : 0;
+    const bool wrap_w = s_tw >= c.ntw;
+    s_tw = wrap_w ? 0 : s_tw;
+    s_th += wrap_w ? 1 : 0;
+  };
+
+  issue_loads();
+  for (int it = 0; it < n_iters; ++it) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // every wave is done reading the previous slab
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) *reinterpret_cast<f32x4*>(A_s + (prow + RPP * j) * LDKK + col4 * 4) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) *reinterpret_cast<f32x4*>(B_s + (prow + RPP * j) * LDKK + col4 * 4) = rb[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // slab visible to every wave
+    issue_loads();                                        // next slab: in flight during the whole burst below
+    __builtin_amdgcn_sched_barrier(0);                    // (hipcc otherwise sinks the fetch below the MFMAs)
+    mma_slab_kc_kc<TM, TN, LDKK, BK / 8>(A_s, B_s, wm0, wn0, lane, acc);
+  }
+
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn0 + tn * 32 + acc_col(lane);
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + tm * 32 + acc_row(r, lane);
+        const int off = out_off_s[row];
+        if (off >= 0) p.out[(size_t)off + n] = acc[tm][tn][r] + bv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Cin = 3 forward (conv1_1, generator_with_attention.py:29): K = 27, HBM-bound on the 32-channel output.
 // 8 lanes per output pixel, 4 output channels each -> a wave stores 1 KiB contiguous per instruction.
 // Weights are HWIO [3][3][3][Cout] read through LDS.
@@ -235,8 +380,28 @@ static void launch_gather(const GatherParams& p, hipStream_t st) {
   hipLaunchKernelGGL((conv_gather_kernel<BM, BN, WGM, WGN>), grid, dim3(256), 0, st, q);
 }
 
+template <int BM, int BN, int WGM, int WGN, int BK>
+static void launch_gather3(const GatherParams& p, hipStream_t st) {
+  int maxwg = 0;
+  GatherParams q = p;
+  for (int i = 0; i < q.ncls; ++i) {
+    q.cls[i].mtiles = sgg_cdiv(q.cls[i].M, BM);
+    const int nwg = q.cls[i].mtiles * (q.N / BN);
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  const unsigned src_bytes = (unsigned)((size_t)q.B * q.Hs * q.Ws * q.C * sizeof(float));
+  dim3 grid(maxwg, q.ncls, 1);
+  hipLaunchKernelGGL((conv_gather3_kernel<BM, BN, WGM, WGN, BK>), grid, dim3(256), 0, st, q, src_bytes);
+}
+
 static int dispatch_gather(const GatherParams& p, hipStream_t st) {
-  if (p.N % 128 == 0)
+  // buffer-load path: byte offsets must stay below the out-of-range marker 2^31
+  const bool small = (size_t)p.B * p.Hs * p.Ws * p.C * sizeof(float) < 0x80000000ull && p.w_bytes < 0x80000000u;
+  if (p.N % 128 == 0 && small)
+    launch_gather3<128, 128, 2, 2, 32>(p, st);   // 64-deep slabs measured 3 % slower (2 instead of 3 waves per SIMD)
+  else if (p.N % 64 != 0 && small)
+    launch_gather3<256, 32, 4, 1, 32>(p, st);     // (N = 64: the v1 kernel measured 95 vs 89 TFLOP/s, kept below)
+  else if (p.N % 128 == 0)
     launch_gather<128, 128, 2, 2>(p, st);
   else if (p.N % 64 == 0)
     launch_gather<256, 64, 4, 1>(p, st);
@@ -278,6 +443,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* 
   p.B = B; p.Hs = Hi; p.Ws = Wi; p.C = Cin; p.N = Cout; p.Ho = Ho; p.Wo = Wo;
   p.sy = stride; p.sx = stride; p.dy = 1; p.dx = 1; p.osy = 1; p.osx = 1; p.KW = KW;
   p.ncls = 1;
+  p.w_bytes = (unsigned)((size_t)KH * KW * Cin * Cout * sizeof(float));
   GatherClass& c = p.cls[0];
   c.Hm = Ho; c.Wm = Wo; c.M = B * Ho * Wo; c.nth = KH; c.ntw = KW; c.oy = -pad_t; c.ox = -pad_l;
   c.kh0 = 0; c.kw0 = 0; c.kstep = 1; c.ooy = 0; c.oox = 0; c.mtiles = 0;
@@ -299,6 +465,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx,
   p.B = B; p.Hs = Ho; p.Ws = Wo; p.C = Cout; p.N = Cin; p.Ho = Hi; p.Wo = Wi;
   p.sy = 1; p.sx = 1; p.dy = -1; p.dx = -1; p.osy = stride; p.osx = stride; p.KW = KW;
   p.ncls = stride * stride;
+  p.w_bytes = (unsigned)((size_t)KH * KW * Cin * Cout * sizeof(float));
   for (int ph = 0; ph < stride; ++ph)
     for (int pw = 0; pw < stride; ++pw) {
       GatherClass& c = p.cls[ph * stride + pw];

@@ -391,13 +391,24 @@ __global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* __re
     }
   }
 }
+// rows [r0, r1) of X summed per column: grid (ceil(cols/256), nchunks); chunk c covers rows [c*rpc, (c+1)*rpc)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int rows, int cols, int ld, float* __restrict__ out,
-                                                     int accumulate) {
+                                                     int out_ld, int rpc, int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += X[(size_t)r * ld + c];
-  out[c] = accumulate ? out[c] + s : s;
+  const int r0 = blockIdx.y * rpc, r1 = min(r0 + rpc, rows);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += X[(size_t)r * ld + c];
+    s1 += X[(size_t)(r + 1) * ld + c];
+    s2 += X[(size_t)(r + 2) * ld + c];
+    s3 += X[(size_t)(r + 3) * ld + c];
+  }
+  for (; r < r1; ++r) s0 += X[(size_t)r * ld + c];
+  const float s = (s0 + s1) + (s2 + s3);
+  float* o = out + (size_t)blockIdx.y * out_ld + c;
+  *o = accumulate ? *o + s : s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -509,10 +520,29 @@ extern "C" int sgg_spatial_mean_bwd(const float* dc0, int ldc, const float* dh0,
   return SGG_OK;
 }
 
-extern "C" int sgg_colsum(const float* X, int rows, int cols, int ld, float* out, int accumulate, void* stream) {
+// tall inputs are reduced in two deterministic stages through `workspace` (sgg_colsum_workspace_bytes)
+static int colsum_chunks(int rows) { return rows > 512 ? (rows + 127) / 128 : 1; }
+extern "C" size_t sgg_colsum_workspace_bytes(int rows, int cols) {
+  const int nc = colsum_chunks(rows);
+  return nc > 1 ? (size_t)nc * cols * sizeof(float) : 0;
+}
+extern "C" int sgg_colsum(const float* X, int rows, int cols, int ld, float* out, int accumulate, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   SGG_CHECK_ARG(X && out && rows > 0 && cols > 0 && ld >= cols, "sgg_colsum: bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3(sgg_cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, X, rows, cols, ld, out,
-                     accumulate);
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = colsum_chunks(rows);
+  if (nc == 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(sgg_cdiv(cols, 256), 1), dim3(256), 0, st, X, rows, cols, ld, out, 0, rows, accumulate);
+  } else {
+    if (!workspace || workspace_bytes < (size_t)nc * cols * sizeof(float)) {
+      sgg_set_error("sgg_colsum: workspace too small");
+      return SGG_ERR_WORKSPACE;
+    }
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(colsum_kernel, dim3(sgg_cdiv(cols, 256), nc), dim3(256), 0, st, X, rows, cols, ld, part, cols, 128, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(sgg_cdiv(cols, 256), 1), dim3(256), 0, st, (const float*)part, nc, cols, cols, out, 0, nc,
+                       accumulate);
+  }
   SGG_LAUNCH_CHECK("sgg_colsum");
   return SGG_OK;
 }

@@ -24,20 +24,22 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
 
-// One 32-deep k-slab of KC x KC tiles: acc[TM][TN] += A_s[wm0 + ..][0..31] * B_s[wn0 + ..][0..31]^T
-template <int TM, int TN>
+// One (8*KB)-deep k-slab of KC x KC tiles with row stride LDK floats:
+// acc[TM][TN] += A_s[wm0 + ..][0 .. 8*KB) * B_s[wn0 + ..][0 .. 8*KB)^T
+// (LDK = 36 for 32-deep slabs, 68 for 64-deep slabs: 68*i mod 64 = 4*i, also conflict free for ds_read_b128)
+template <int TM, int TN, int LDK = SGG_LDK, int KB = 4>
 __device__ __forceinline__ void mma_slab_kc_kc(const float* __restrict__ A_s, const float* __restrict__ B_s,
                                                int wm0, int wn0, int lane, f32x16 (&acc)[TM][TN]) {
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
+  for (int kb = 0; kb < KB; ++kb) {
     f32x4 a[TM], b[TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
-      a[tm] = *reinterpret_cast<const f32x4*>(A_s + (wm0 + tm * 32 + i) * SGG_LDK + kb * 8 + 4 * h);
+      a[tm] = *reinterpret_cast<const f32x4*>(A_s + (wm0 + tm * 32 + i) * LDK + kb * 8 + 4 * h);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
-      b[tn] = *reinterpret_cast<const f32x4*>(B_s + (wn0 + tn * 32 + i) * SGG_LDK + kb * 8 + 4 * h);
+      b[tn] = *reinterpret_cast<const f32x4*>(B_s + (wn0 + tn * 32 + i) * LDK + kb * 8 + 4 * h);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll

@@ -48,7 +48,8 @@ SIGNATURES = {
     "sgg_attn_step_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_lnlstm_gates_fwd": (_i, [_vp] * 9 + [_i, _i, _vp]),
     "sgg_lnlstm_gates_bwd": (_i, [_vp] * 7 + [_i] + [_vp] * 7 + [_i, _vp]),
-    "sgg_colsum": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "sgg_colsum_workspace_bytes": (_sz, [_i, _i]),
+    "sgg_colsum": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "sgg_onehot": (_i, [_vp, _vp, _i, _i, _vp]),
     "sgg_interpolate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sgg_wgan_gp_loss_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -127,8 +128,8 @@ class HipKernels:
     def gather_symbol(n_out):
         """Kernel symbol the implicit-GEMM dispatcher (csrc/conv_gather.hip: dispatch_gather) picks for N outputs."""
         if n_out % 128 == 0:
-            return "conv_gather_kernel<128,128,2,2>"
-        return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather_kernel<256,32,4,1>"
+            return "conv_gather3_kernel<128,128,2,2,32>"
+        return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather3_kernel<256,32,4,1,32>"
 
     # -- plumbing ------------------------------------------------------------------------------------
     def _stream(self):
@@ -328,7 +329,9 @@ class HipKernels:
         self._dev(X, out)
         rows, cols = X.shape
         assert X.stride(1) == 1
-        self._check(self.lib.sgg_colsum(_p(X), rows, cols, _ld(X), _p(out), int(accumulate), self._stream()), "sgg_colsum")
+        ws = self.workspace(self.lib.sgg_colsum_workspace_bytes(rows, cols))
+        self._check(self.lib.sgg_colsum(_p(X), rows, cols, _ld(X), _p(out), int(accumulate), _p(ws), ws.numel(), self._stream()),
+                    "sgg_colsum")
 
     # -- loss / optimiser / misc -----------------------------------------------------------------------
     def onehot(self, labels, out):

@@ -1,0 +1,4 @@
+set -e
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python -m pytest tests -m gpu -q 2>&1 | tail -2
+bash scripts/gpu_bench_short.sh

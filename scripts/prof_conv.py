@@ -1,0 +1,32 @@
+"""Micro-driver for profiling one conv shape: python scripts/prof_conv.py B H Cin Cout k stride [reps] [mode]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import sgg_amd
+from sgg_amd.lib import HipKernels, same_pads
+
+B, H, Ci, Co, k, s = [int(x) for x in sys.argv[1:7]]
+reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+mode = sys.argv[8] if len(sys.argv) > 8 else "fwd"
+K = HipKernels("cuda:0")
+x = torch.randn((B, H, H, Ci), device="cuda")
+w = torch.randn((k, k, Ci, Co), device="cuda") * 0.05
+b = torch.randn((Co,), device="cuda")
+Ho = same_pads(H, k, s)[0]
+y = torch.empty((B, Ho, Ho, Co), device="cuda")
+dy = torch.randn((B, Ho, Ho, Co), device="cuda")
+dx = torch.empty_like(x); dw = torch.empty_like(w)
+wf = torch.empty((k, k, Co, Ci), device="cuda"); K.hwio_to_hwoi(w, wf)
+def run():
+    if mode == "fwd": K.conv_fwd(x, w, wf, b, y, s)
+    elif mode == "dgrad": K.conv_dgrad(dy, w, dx, s)
+    else: K.conv_wgrad(x, dy, dw, s)
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+fl = 2.0 * B * Ho * Ho * Co * k * k * Ci
+print("%s B%d H%d %d->%d k%d s%d: %.3f ms  %.1f TFLOP/s" % (mode, B, H, Ci, Co, k, s, ms, fl / ms / 1e9))

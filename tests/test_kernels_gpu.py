@@ -254,7 +254,7 @@ def test_spatial_mean_colsum(hip, ref):
     d = dev(dctx0)
     hip.spatial_mean_bwd(dev(dc0), dev(dh0), d, True)
     close(d, dref, what="spatial_mean_bwd")
-    X = rnd((37, 5120), 64)
+    X = rnd((1337, 5120), 64)
     out = dev(rnd((5120,), 65))
     exp = out.cpu().double() + X.double().sum(0)
     hip.colsum(dev(X), out, True)
