@@ -173,7 +173,11 @@ def main():
             out["kernel_time_s"] = {s: round(v[2], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][2])}
             out["kernel_tflops"] = {s: round(v[1] / v[2] / 1e12, 2) for s, v in per.items() if v[2] > 0}
         if world == 1 and args.cpu_rows > 0:
-            out["cpu_baseline"] = cpu_baseline(S, V, args.cpu_rows, os.cpu_count() or 1)
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(S, V, args.cpu_rows, min(ncpu, 16))   # a 1-GPU box grants 16 host cores
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

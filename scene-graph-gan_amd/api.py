@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference's model classes (shared by architectures/*.py): lazily builds the network for
+the first (batch, image size) it sees, shares weights across builds (tf.AUTO_REUSE, train.py:86,91) and exposes the
+attributes the reference sets on `self` (generator_with_attention.py:16,68,74,75)."""
+from __future__ import annotations
+
+import torch
+
+from .lib import HipKernels
+from .params import EMBED_DIM, FEAT_C, init_state_dict
+from .step import Network
+
+_KERNELS = {}
+
+
+def kernels_for(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("scene-graph-gan_amd runs on MI355X GPUs only (tensor on %s): there is no CPU fallback" % device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _KERNELS:
+        _KERNELS[key] = HipKernels("cuda:%d" % key)
+    return _KERNELS[key]
+
+
+class NetworkHandle(object):
+    def __init__(self, kind, vocab_size):
+        self.kind, self.vocab_size = kind, int(vocab_size)
+        self.net = None
+        self.embedding_matrix = None
+        self.init_seed = 3
+
+    def _ensure(self, images):
+        """Create the network (parameters with the reference's initialisers) on first use; later calls must use
+        the same static shape (the reference also needs a static spatial size, generator_with_attention.py:15)."""
+        assert images.dim() == 4 and images.shape[3] == 3 and images.shape[1] == images.shape[2], "images must be NHWC [B,S,S,3]"
+        B, S = int(images.shape[0]), int(images.shape[1])
+        if self.net is None:
+            K = kernels_for(images.device)
+            E = EMBED_DIM if self.embedding_matrix is None else int(self.embedding_matrix.shape[1])
+            sd = init_state_dict(self.kind, self.vocab_size, S, E, seed=self.init_seed)
+            if self.kind == "D" and self.embedding_matrix is not None:
+                sd["W"] = torch.as_tensor(self.embedding_matrix).detach().float().cpu()
+            self.net = Network(K, self.kind, self.vocab_size, S, B, E, state_dict=sd)
+            if self.kind == "D":
+                self.embedding_matrix = self.net.arena.views["W"]
+        if (self.net.trunk.B, self.net.trunk.S) != (B, S):
+            raise ValueError("network was built for batch %d, size %d; got %d, %d" % (self.net.trunk.B, self.net.trunk.S, B, S))
+        return self.net
+
+    def _publish(self, ctx, st):
+        B, L = ctx.shape[0], ctx.shape[1]
+        side = int(round(L ** 0.5))
+        self._ctx = ctx
+        self.downsampled = ctx.view(B, side, side, FEAT_C)
+        self.flattened_context = ctx.view(B, L * FEAT_C)
+        self.partially_flattened_context = ctx
+        self.alpha = st.AL[-1][0]
+
+    def _attention(self, cell_state):
+        """attentionMechanism: z_hat for an arbitrary (c, h) state on the current feature map."""
+        net, ctx = self.net, self._ctx
+        B, L = ctx.shape[0], ctx.shape[1]
+        c = cell_state[0].contiguous()
+        K = net.K
+        ec = torch.empty((1, B, L), device=c.device)
+        al = torch.empty((1, B, L), device=c.device)
+        z = torch.empty((1, B, FEAT_C), device=c.device)
+        K.gemm_nn(c, net.head.W_c, ec[0])
+        K.attn_step_fwd(net.head.P, ec, ctx, al, z)
+        self.alpha = al[0]
+        return z[0]
+
+    def state_dict(self, full_names=True):
+        return self.net.arena.state_dict(full_names)
+
+    def load_state_dict(self, sd):
+        self.net.arena.load_state_dict(sd)
+        self.net.trunk.refresh_weights()

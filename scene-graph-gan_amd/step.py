@@ -75,10 +75,11 @@ class GanStep:
     """The training hot path for a fixed (B, S, V). `reducer(network)` (optional) all-reduces network.grad_flat
     across data-parallel ranks and returns the scale to apply to the gradient (1/world_size)."""
 
-    def __init__(self, K, V, S, B, lam=10.0, E=EMBED_DIM, g_state=None, d_state=None, dtype=torch.float32, reducer=None):
+    def __init__(self, K, V, S, B, lam=10.0, E=EMBED_DIM, g_state=None, d_state=None, dtype=torch.float32, reducer=None,
+                 G=None, D=None):
         self.K, self.V, self.S, self.B, self.lam = K, V, S, B, float(lam)
-        self.G = Network(K, "G", V, S, B, E, dtype=dtype, state_dict=g_state)
-        self.D = Network(K, "D", V, S, B, E, dtype=dtype, state_dict=d_state)
+        self.G = G if G is not None else Network(K, "G", V, S, B, E, dtype=dtype, state_dict=g_state)
+        self.D = D if D is not None else Network(K, "D", V, S, B, E, dtype=dtype, state_dict=d_state)
         self.reducer = reducer
         dev = self.G.arena.flat.device
         z = lambda *s: torch.zeros(s, device=dev, dtype=dtype)

@@ -1,0 +1,70 @@
+"""-m gpu: the drop-in boundary (architectures.* classes with the reference's signatures, train.py plumbing)
+against the oracle on BASELINE.json configs[0] (8 x 64x64 images, vocab 50).  Tolerance 1e-4 + 1e-4*|ref| (fp32)."""
+import os
+
+import pytest
+import torch
+
+from oracle import sgg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, what):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    tol = 1e-4 + 1e-4 * float(b.abs().max())
+    assert float((a - b).abs().max()) <= tol, "%s: %.3e > %.3e" % (what, float((a - b).abs().max()), tol)
+
+
+def test_generator_discriminator_classes_match_oracle():
+    from architectures.generator_with_attention import Generator
+    from architectures.discriminator_with_attention import Discriminator
+    B, S, V = 8, 64, 50
+    gp, dp = O.init_params("G", V, S), O.init_params("D", V, S)      # same initialisers + seed as the product default
+    images, labels, onehot = O.synth_batch(B, S, V)
+    noise = O.synth_noise(B, 0)
+    g = Generator(V)
+    logits = g.build_generator(images.cuda(), True, noise=noise.cuda())
+    ref = O.generator_forward(gp, images, noise)
+    close(logits, ref, "Generator.build_generator")
+    assert tuple(g.downsampled.shape) == (B, 4, 4, 512) and tuple(g.flattened_context.shape) == (B, 16 * 512)
+    assert tuple(g.partially_flattened_context.shape) == (B, 16, 512) and tuple(g.alpha.shape) == (B, 16)
+    # weights are shared across builds (AUTO_REUSE): a second build gives the same result
+    close(g.build_generator(images.cuda(), True, noise=noise.cuda()), ref, "second build")
+    # attentionMechanism on an arbitrary state
+    feat = O.encoder(gp, images)
+    ctx_flat, ctx, m = O.context_views(feat)
+    c = torch.randn(B, 512, generator=torch.Generator().manual_seed(5))
+    z_ref, al_ref = O.attention(gp, ctx_flat, ctx, c)
+    z = g.attentionMechanism((c.cuda(), c.cuda()))
+    close(z, z_ref, "Generator.attentionMechanism")
+    close(g.alpha, al_ref, "alpha")
+    # critic
+    d = Discriminator(V, dp["W"].clone())
+    out = d.build_discriminator(onehot.cuda(), images.cuda())
+    close(out, O.discriminator_forward(dp, onehot, images), "Discriminator.build_discriminator(real)")
+    out = d.build_discriminator(ref.cuda(), images.cuda())
+    close(out, O.discriminator_forward(dp, ref, images), "Discriminator.build_discriminator(fake)")
+    assert tuple(out.shape) == (B, 3, 1)
+    assert d.embedding_matrix.data_ptr() == d.net.arena.views["W"].data_ptr()
+    with pytest.raises(RuntimeError):
+        Generator(V).build_generator(images, True)          # CPU tensor: no fallback
+
+
+def test_train_entry_point_synthetic(tmp_path):
+    import train as T
+    gan = T.SceneGraphGAN(str(tmp_path / "ck"), str(tmp_path / "logs"), None, None, None, None, None,
+                          critic_iters=2, batch_size=8, lambda_=10, resume=False, synthetic=(8, 64, 50))
+    gan.train(max_iterations=2, log_every=1)
+    assert os.path.exists(gan._ckpt_path())
+    d = gan.step.d_losses.cpu()
+    assert torch.isfinite(d).all() and gan.step.D.adam_t == 4 and gan.step.G.adam_t == 2
+    w_before = gan.g.net.arena.flat.clone()
+    images, _ = gan._next_batch(0)
+    toks, words = gan.sample_triples(images)
+    assert tuple(toks.shape) == (8, 3) and len(words) == 8 and len(words[0]) == 3
+    # resume picks the weights and Adam state up again
+    gan2 = T.SceneGraphGAN(str(tmp_path / "ck"), str(tmp_path / "logs"), None, None, None, None, None,
+                           critic_iters=2, batch_size=8, lambda_=10, resume=True, synthetic=(8, 64, 50))
+    gan2.train(max_iterations=2)
+    assert gan2.itr == 2 and torch.equal(gan2.g.net.arena.flat, w_before) and gan2.step.D.adam_t == 4

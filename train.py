@@ -1,0 +1,227 @@
+"""Entry point mirroring the reference's train.py (class SceneGraphGAN + the same CLI flags), MI355X-native.
+
+    python train.py --synthetic 64,224,1000 --max_iterations 20           # no Visual Genome files needed
+    python train.py --path_to_ims_to_triples ... --path_to_vocab ... --path_to_word_embeddings ...
+
+Reference: train.py:17-422.  Kept: constructor signature (:23-24), `_Generator` / `_Discriminator` wrappers with
+shared weights (:85-93), the loss / optimiser definition (:239-266) and the loop body (:362-368: CRITIC_ITERS critic
+updates then one generator update on the same minibatch, fresh noise / alpha per update).  The TensorFlow graph /
+tfgan / tf.data machinery is replaced by sgg_amd.step.GanStep (hand-written HIP kernels behind libsgg_hip.so).
+Deviations, all documented in SURVEY.md Appendix C: flags are passed by keyword (the reference swaps batch_size and
+critic_iters, C-2); the checkpoint directory is not wiped when resuming and checkpoints are actually written (C-5);
+evaluation uses the trained weights (C-4).  Multi-GPU: launch with torch.distributed.run, one process per GPU.
+"""
+import os, sys
+sys.path.append(os.getcwd())
+
+import argparse
+import json
+import time
+
+import numpy as np
+import torch
+
+from architectures.generator_with_attention import Generator
+from architectures.discriminator_with_attention import Discriminator
+
+import sgg_amd  # noqa: F401
+from sgg_amd import dp as dpmod
+from sgg_amd.api import kernels_for
+from sgg_amd.params import EMBED_DIM
+from sgg_amd.step import GanStep
+
+
+class SceneGraphGAN(object):
+
+    ############################################################
+    ## All init methods
+    ############################################################
+    def __init__(self, checkpoints_dir, summaries_dir, path_to_ims_to_triples, path_to_vocab, path_to_word_embeddings,
+                 path_to_image_means, path_to_image_stds, critic_iters, batch_size, lambda_, resume,
+                 synthetic=None, device=None, seed=0):
+        # Hyperparameters (train.py:26-32)
+        self.CRITIC_ITERS = int(critic_iters)
+        self.BATCH_SIZE = int(batch_size)
+        self.VAL_BATCH_SIZE = self.BATCH_SIZE // 2
+        self.TEST_BATCH_SIZE = self.BATCH_SIZE // 2
+        self.TEST_BATCH_MULTIPLIER = 8
+        self.LAMBDA = float(lambda_)
+        self.resume = bool(resume)
+        self.checkpoints_dir, self.summaries_dir = checkpoints_dir, summaries_dir
+        self.rank, self.world, local = dpmod.init_from_env()
+        self.device = torch.device(device if device is not None else "cuda:%d" % local)
+        torch.cuda.set_device(self.device)
+        if self.rank == 0:
+            os.makedirs(checkpoints_dir, exist_ok=True)
+            os.makedirs(summaries_dir, exist_ok=True)
+        self.seed = seed
+        if synthetic is not None:
+            B, S, V = synthetic
+            self.BATCH_SIZE, self.image_size = B, S
+            self.vocab = {"w%d" % i: i for i in range(V)}
+            g = torch.Generator().manual_seed(3)
+            self.embeddings = (torch.rand((V, EMBED_DIM), generator=g) * 0.2 - 0.1).numpy()   # map_files_to_triples.py:24
+            self.dataset = None
+        else:
+            self.image_size = 221                                           # train.py:171
+            with open(path_to_ims_to_triples, "r") as f:
+                self.ims_to_triples = json.load(f)
+            with open(path_to_vocab, "r") as f:
+                self.vocab = json.load(f)
+            self.embeddings = np.load(path_to_word_embeddings)
+            self._loadImageMeans(path_to_image_means, path_to_image_stds)
+            self.dataset = self._gatherFiles()
+        self._createStringMappings()
+        self.g = Generator(len(self.vocab))
+        self.d = Discriminator(len(self.vocab), torch.as_tensor(self.embeddings, dtype=torch.float32))
+        self.step = None
+        self.itr = 0
+
+    def _createStringMappings(self):
+        self.reverse_vocab = {y: x for x, y in self.vocab.items()}                          # train.py:76-80
+
+    def _loadImageMeans(self, path_means, path_stds):
+        with open(path_means) as f:
+            self.image_means = torch.tensor([float(l.strip()) for l in f if l.strip()])
+        with open(path_stds) as f:
+            self.image_stds = torch.tensor([float(l.strip()) for l in f if l.strip()])
+
+    def _Generator(self, images, is_training=True):
+        return self.g.build_generator(images, is_training)
+
+    def _Discriminator(self, triple_input, images, is_training=True):
+        return self.d.build_discriminator(triple_input, images, is_training)
+
+    ############################################################
+    ## Data (train.py:114-226); synthetic mode needs no files
+    ############################################################
+    def _gatherFiles(self):
+        keys = list(self.ims_to_triples.keys())
+        train_keys = keys[:int(0.9 * len(keys))]
+        files, labels = [], []
+        for k in train_keys:
+            for t in self.ims_to_triples[k]:
+                files.append(k)
+                labels.append(t)
+        perm = np.random.RandomState(self.seed).permutation(len(files))
+        files, labels = [files[i] for i in perm], np.asarray(labels, dtype=np.int64)[perm]
+        thr = int(0.88 * len(files))
+        self.max_iterations = 5 * thr
+        return {"train": (files[:thr], labels[:thr]), "val": (files[thr:], labels[thr:])}
+
+    def _parseFunction(self, filename):
+        """JPEG decode -> bilinear resize 221x221 -> (x - mean) / std (train.py:168-174), on the host."""
+        from PIL import Image
+        im = Image.open(filename).convert("RGB").resize((221, 221), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(im, dtype=np.float32))
+        return (x - self.image_means) / self.image_stds
+
+    def _next_batch(self, it):
+        B = self.BATCH_SIZE
+        if self.dataset is None:
+            g = torch.Generator().manual_seed(self.seed + 17 * it + 1000 * self.rank)
+            images = torch.randn((B, self.image_size, self.image_size, 3), generator=g)
+            labels = torch.randint(0, len(self.vocab), (B, 3), generator=g, dtype=torch.int64)
+        else:
+            files, labs = self.dataset["train"]
+            idx = [(it * B * self.world + self.rank * B + j) % len(files) for j in range(B)]
+            images = torch.stack([self._parseFunction(files[i]) for i in idx])
+            labels = torch.from_numpy(labs[idx])
+        return images.to(self.device), labels.to(self.device)
+
+    ############################################################
+    ## Saving
+    ############################################################
+    def _ckpt_path(self):
+        return os.path.join(self.checkpoints_dir, "model.ckpt.pt")
+
+    def _saveModel(self):
+        self.step.flush()
+        if self.rank == 0:
+            torch.save({"itr": self.itr, "G": self.g.state_dict(), "D": self.d.state_dict(),
+                        "G_adam": (self.step.G.m_flat.cpu(), self.step.G.v_flat.cpu(), self.step.G.adam_t),
+                        "D_adam": (self.step.D.m_flat.cpu(), self.step.D.v_flat.cpu(), self.step.D.adam_t)}, self._ckpt_path())
+
+    def _loadModel(self):
+        ck = torch.load(self._ckpt_path(), map_location="cpu")
+        self.g.load_state_dict(ck["G"])
+        self.d.load_state_dict(ck["D"])
+        for net, key in ((self.step.G, "G_adam"), (self.step.D, "D_adam")):
+            net.m_flat.copy_(ck[key][0]); net.v_flat.copy_(ck[key][1]); net.adam_t = ck[key][2]
+        self.itr = ck["itr"]
+
+    ############################################################
+    ## Training (train.py:341-388)
+    ############################################################
+    def _constructOps(self, images):
+        """Build both networks for this static shape and wire the WGAN-GP step (train.py:231-266)."""
+        B, S, V = images.shape[0], images.shape[1], len(self.vocab)
+        g_net, d_net = self.g._ensure(images), self.d._ensure(images)
+        reducer = dpmod.GradReducer() if self.world > 1 else None
+        self.step = GanStep(kernels_for(self.device), V, S, B, lam=self.LAMBDA, G=g_net, D=d_net, reducer=reducer)
+
+    def train(self, max_iterations=None, log_every=10, save_every=0):
+        images, labels = self._next_batch(0)
+        self._constructOps(images)
+        if self.resume and os.path.exists(self._ckpt_path()):
+            self._loadModel()
+        n_it = max_iterations if max_iterations is not None else getattr(self, "max_iterations", 1000)
+        gen = torch.Generator().manual_seed(self.seed + 7 + self.rank)
+        log = open(os.path.join(self.summaries_dir, "losses.jsonl"), "a") if self.rank == 0 else None
+        B, t0 = self.BATCH_SIZE, time.time()
+        while self.itr < n_it:
+            images, labels = self._next_batch(self.itr)
+            for _ in range(self.CRITIC_ITERS):                                      # train.py:364-365
+                noise = torch.randn((B, 512), generator=gen).to(self.device)
+                alpha = torch.rand((B,), generator=gen).to(self.device)
+                self.step.critic_step(images, labels, noise, alpha)
+            noise = torch.randn((B, 512), generator=gen).to(self.device)
+            self.step.generator_step(images, noise)                                 # train.py:368
+            self.itr += 1
+            if log is not None and self.itr % log_every == 0:
+                d, g = self.step.d_losses.cpu().tolist(), self.step.g_losses.cpu().tolist()
+                rate = B * self.world * self.itr / (time.time() - t0)
+                rec = {"itr": self.itr, "disc_loss": d[0], "gen_loss": -g[3], "gp": d[2], "triples_per_s": rate}
+                log.write(json.dumps(rec) + "\n"); log.flush()
+                print(rec)
+            if save_every and self.itr % save_every == 0:
+                self._saveModel()
+        self._saveModel()
+
+    def sample_triples(self, images, noise=None):
+        """tf.argmax(fake_inputs, -1) -> words (train.py:269-275), with the trained weights."""
+        logits = self._Generator(images, False) if noise is None else self.g.build_generator(images, False, noise)
+        toks = torch.empty((images.shape[0], 3), dtype=torch.int64, device=images.device)
+        kernels_for(images.device).argmax_rows(logits, toks.view(-1))
+        return toks, [[self.reverse_vocab.get(int(i), "UNK") for i in row] for row in toks.cpu()]
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--checkpoints_dir", help="Where to save the checkpoints", default="./checkpoints")
+    parser.add_argument("--summaries_dir", help="Where to write the logs", default="./logs")
+    parser.add_argument("--path_to_ims_to_triples", default="./dataset_creation/ims_to_triples.json")
+    parser.add_argument("--path_to_vocab", default="./dataset_creation/vocab.json")
+    parser.add_argument("--path_to_word_embeddings", default="./dataset_creation/word_embeddings.npy")
+    parser.add_argument("--path_to_image_means", default="./dataset_creation/image_means.txt")
+    parser.add_argument("--path_to_image_stds", default="./dataset_creation/image_stds.txt")
+    parser.add_argument("--batch_size", default=64, help="Batch size defaults", type=int)
+    parser.add_argument("--critic_iters", default=10, help="Number of critic iterations per generator iteration", type=int)
+    parser.add_argument("--lambda", default=10, help="WGAN Lipschitz Penalty", type=int)
+    parser.add_argument("--resume", default=False, help="Resume from the last checkpoint", type=bool)
+    parser.add_argument("--GPU", default="0", help="Which GPU to use (single-process runs)")
+    parser.add_argument("--synthetic", default=None, help="B,S,V: train on synthetic tensors of that shape (no dataset files)")
+    parser.add_argument("--max_iterations", default=None, type=int)
+    args = parser.parse_args()
+    params = vars(args)
+
+    if "LOCAL_RANK" not in os.environ:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", "{}".format(params["GPU"]))
+    synthetic = tuple(int(x) for x in params["synthetic"].split(",")) if params["synthetic"] else None
+    gan = SceneGraphGAN(checkpoints_dir=params["checkpoints_dir"], summaries_dir=params["summaries_dir"],
+                        path_to_ims_to_triples=params["path_to_ims_to_triples"], path_to_vocab=params["path_to_vocab"],
+                        path_to_word_embeddings=params["path_to_word_embeddings"],
+                        path_to_image_means=params["path_to_image_means"], path_to_image_stds=params["path_to_image_stds"],
+                        critic_iters=params["critic_iters"], batch_size=params["batch_size"], lambda_=params["lambda"],
+                        resume=params["resume"], synthetic=synthetic)
+    gan.train(max_iterations=params["max_iterations"])
