@@ -1,0 +1,39 @@
+"""Copy the judged summaries of one gpurun profile directory into profiles/ and derive the roofline `traffic` value.
+   python scripts/summarize_profiles.py gpurun_out/r01 r01"""
+import csv, json, os, shutil, sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), os.path.join(dst, "%s_rocprofv3_kernel_stats.csv" % tag))
+for f in ("bench.json", "bench_under_rocprof.json", "pytest_gpu.log"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            a = acc[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return acc
+
+
+fetch = per_kernel(os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+write = per_kernel(os.path.join(src, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
+rows, traffic = [], {}
+for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+    n, f = fetch[k]
+    w = write.get(k, [0, 0.0])[1]
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
+    # bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+    per_launch = (2.0 * f + w) * 1024.0 / max(n, 1)
+    rows.append({"kernel": k, "launches": n, "fetch_kib_raw_sum": f, "write_kib_sum": w, "hbm_bytes_per_launch_corrected": per_launch})
+    short = k.replace("void ", "").split("(")[0].replace(" ", "")
+    traffic[short] = per_launch
+json.dump(rows, open(os.path.join(dst, "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+print("wrote", os.listdir(dst))
