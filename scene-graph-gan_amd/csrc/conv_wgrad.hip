@@ -15,6 +15,8 @@ struct WgradParams {
   float* out;  // [nsplit][taps][Cin][Cout]
   int B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l;
   int Mpix, chunk, ntile_n;
+  unsigned magic_wo, magic_ho;   // ceil(2^32 / Wo), ceil(2^32 / Ho): exact division by __umulhi for our ranges
+  unsigned x_bytes, dy_bytes;    // buffer descriptor bounds
 };
 
 template <int BMC, int BNC, int WM, int WN>
@@ -48,45 +50,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   acc_zero<TM, TN>(acc);
 
   constexpr int A_CPR = BMC / 4, B_CPR = BNC / 4;  // float4 per row
+  // Branch-free slab fetch (same recipe as conv_gather3_kernel): raw buffer loads, rows past the pixel range or
+  // outside the image get an out-of-range offset and read as zeros; pixel -> (b, ho, wo) by multiply-high.
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
   f32x4 ra[NPA], rb[NPB];
   auto issue_loads = [&](int pix0) {
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
       const int pi = tid + 256 * j;
       const int row = pi / A_CPR, c4 = pi % A_CPR;
-      const int pix = pix0 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pix < pix_end) {
-        const int wo = pix % p.Wo;
-        const int t = pix / p.Wo;
-        const int ho = t % p.Ho;
-        const int b = t / p.Ho;
-        const int yy = ho * p.stride - p.pad_t + kh, xx = wo * p.stride - p.pad_l + kw;
-        if ((unsigned)yy < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi)
-          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(b * p.Hi + yy) * p.Wi + xx) * p.Cin + ci0 + c4 * 4);
-      }
-      ra[j] = v;
+      const unsigned pix = (unsigned)(pix0 + row);
+      const unsigned t = __umulhi(pix, p.magic_wo);          // pix / Wo
+      const int wo = (int)(pix - t * (unsigned)p.Wo);
+      const unsigned b = __umulhi(t, p.magic_ho);            // t / Ho
+      const int ho = (int)(t - b * (unsigned)p.Ho);
+      const int yy = ho * p.stride - p.pad_t + kh, xx = wo * p.stride - p.pad_l + kw;
+      const unsigned bad = (unsigned)((int)pix >= pix_end) | (unsigned)((unsigned)yy >= (unsigned)p.Hi) |
+                           (unsigned)((unsigned)xx >= (unsigned)p.Wi);
+      const unsigned off = (unsigned)((((int)b * p.Hi + yy) * p.Wi + xx) * p.Cin + ci0 + c4 * 4) * 4u;
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off | ((0u - bad) & 0x80000000u), 0, 0));
     }
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
       const int pi = tid + 256 * j;
       const int row = pi / B_CPR, c4 = pi % B_CPR;
       const int pix = pix0 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pix < pix_end) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)pix * p.Cout + co0 + c4 * 4);
-      rb[j] = v;
+      const unsigned bad = (unsigned)(pix >= pix_end);
+      const unsigned off = (unsigned)(pix * p.Cout + co0 + c4 * 4) * 4u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off | ((0u - bad) & 0x80000000u), 0, 0));
     }
   };
 
-  if (pix_begin < pix_end) issue_loads(pix_begin);
+  issue_loads(pix_begin);
   for (int pix0 = pix_begin; pix0 < pix_end; pix0 += 32) {
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int j = 0; j < NPA; ++j) *reinterpret_cast<f32x4*>(A_s + (tid + 256 * j) * 4) = ra[j];
 #pragma unroll
     for (int j = 0; j < NPB; ++j) *reinterpret_cast<f32x4*>(B_s + (tid + 256 * j) * 4) = rb[j];
-    __syncthreads();
-    if (pix0 + 32 < pix_end) issue_loads(pix0 + 32);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_loads(pix0 + 32);                               // past pix_end: zeros, no traffic
+    __builtin_amdgcn_sched_barrier(0);
     mma_slab_mc_mc<TM, TN>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
   }
 
@@ -266,6 +273,15 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW;
   p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.Mpix = B * Ho * Wo; p.chunk = pl.chunk; p.ntile_n = Cout / pl.bnc;
+  p.magic_wo = (unsigned)((0x100000000ull + Wo - 1) / Wo);
+  p.magic_ho = (unsigned)((0x100000000ull + Ho - 1) / Ho);
+  p.x_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
+  p.dy_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
+  // multiply-high division is exact while n * d < 2^32 (n = pixel index + 31, d = Wo; then n / Wo and Ho)
+  SGG_CHECK_ARG(Ho >= 2 && Wo >= 2, "sgg_conv2d_nhwc_wgrad: output grid must be at least 2x2");
+  SGG_CHECK_ARG(((unsigned long long)B * Ho * Wo + 64) * (unsigned long long)Wo < 0x100000000ull &&
+                    (size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull && (size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull,
+                "sgg_conv2d_nhwc_wgrad: tensor too large for the 32-bit offset path");
   dim3 grid(pl.tiles, KH * KW, pl.nsplit);
 #define SGG_WG(BMC, BNC, WM, WN) \
   hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN>), grid, dim3(256), 0, st, p)
