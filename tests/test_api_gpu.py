@@ -68,3 +68,34 @@ def test_train_entry_point_synthetic(tmp_path):
                            critic_iters=2, batch_size=8, lambda_=10, resume=True, synthetic=(8, 64, 50))
     gan2.train(max_iterations=2)
     assert gan2.itr == 2 and torch.equal(gan2.g.net.arena.flat, w_before) and gan2.step.D.adam_t == 4
+
+
+def test_real_data_pipeline_and_evaluation(tmp_path):
+    """f1 + f3 rows: the reference's on-disk formats (ims_to_triples.json, vocab.json, word_embeddings.npy [V,300] float64,
+    image_means/stds.txt), JPEG -> 221x221 -> standardise, one training iteration, checkpoint, R@50/R@100."""
+    import json
+    import numpy as np
+    from PIL import Image
+    import train as T
+    rng = np.random.RandomState(0)
+    V = 20
+    ims = {}
+    for i in range(12):
+        path = str(tmp_path / ("im%d.jpg" % i))
+        Image.fromarray(rng.randint(0, 255, (40 + i, 50, 3), dtype=np.uint8)).save(path)
+        ims[path] = rng.randint(0, V, (3, 3)).tolist()
+    (tmp_path / "ims.json").write_text(json.dumps(ims))
+    (tmp_path / "vocab.json").write_text(json.dumps({"w%d" % i: i for i in range(V)}))
+    np.save(str(tmp_path / "emb.npy"), rng.uniform(-0.1, 0.1, (V, 300)))
+    (tmp_path / "means.txt").write_text("119.6\n115.1\n106.1\n")
+    (tmp_path / "stds.txt").write_text("30.4\n30.5\n36.7\n")
+    gan = T.SceneGraphGAN(str(tmp_path / "ck"), str(tmp_path / "logs"), str(tmp_path / "ims.json"), str(tmp_path / "vocab.json"),
+                          str(tmp_path / "emb.npy"), str(tmp_path / "means.txt"), str(tmp_path / "stds.txt"),
+                          critic_iters=1, batch_size=4, lambda_=10, resume=False)
+    images, labels = gan._next_batch(0)
+    assert tuple(images.shape) == (4, 221, 221, 3) and tuple(labels.shape) == (4, 3)
+    assert abs(float(images.mean())) < 3.0            # standardised
+    gan.train(max_iterations=1)
+    assert torch.isfinite(gan.step.d_losses).all() and os.path.exists(gan._ckpt_path())
+    r50, r100 = gan.test(max_images=1, out_path=str(tmp_path / "recalls.txt"))
+    assert 0.0 <= r50 <= 1.0 and 0.0 <= r100 <= 1.0 and os.path.exists(str(tmp_path / "recalls.txt"))

@@ -98,6 +98,7 @@ class SceneGraphGAN(object):
     def _gatherFiles(self):
         keys = list(self.ims_to_triples.keys())
         train_keys = keys[:int(0.9 * len(keys))]
+        self.test_items = [(k, self.ims_to_triples[k]) for k in keys[int(0.9 * len(keys)):] if len(self.ims_to_triples[k])]
         files, labels = [], []
         for k in train_keys:
             for t in self.ims_to_triples[k]:
@@ -187,6 +188,54 @@ class SceneGraphGAN(object):
             if save_every and self.itr % save_every == 0:
                 self._saveModel()
         self._saveModel()
+
+    ############################################################
+    ## Testing (train.py:294-335)
+    ############################################################
+    def _recall(self, fake, real, N):
+        return float(len(set(map(tuple, fake)).intersection(set(map(tuple, real))))) / N
+
+    def test(self, max_images=None, out_path="recalls.txt"):
+        """R@50 / R@100 as the reference computes them: per test image, TEST_BATCH_MULTIPLIER x TEST_BATCH_SIZE
+        generator samples, scored by the mean critic output over the three steps, sorted ascending
+        (`score_accumulator.argsort()`, train.py:321), the first 50 / 100 compared as sets with the image's true
+        triples.  Uses the trained weights (the reference's test ops use an untrained copy)."""
+        if self.step is None:
+            images, _ = self._next_batch(0)
+            self._constructOps(images)
+        self.step.flush()
+        B, K = self.BATCH_SIZE, kernels_for(self.device)
+        n_samples = self.TEST_BATCH_MULTIPLIER * self.TEST_BATCH_SIZE
+        passes = max(1, -(-n_samples // B))
+        if self.dataset is None:
+            g = torch.Generator().manual_seed(self.seed + 99)
+            items = [(torch.randn((self.image_size, self.image_size, 3), generator=g),
+                      torch.randint(0, len(self.vocab), (5, 3), generator=g).tolist()) for _ in range(max_images or 2)]
+        else:
+            items = [(self._parseFunction(k), t) for k, t in self.test_items[:max_images]]
+        gen = torch.Generator().manual_seed(self.seed + 123)
+        toks = torch.empty((B, 3), dtype=torch.int64, device=self.device)
+        r50, r100 = [], []
+        for image, triples in items:
+            images = image.unsqueeze(0).expand(B, -1, -1, -1).contiguous().to(self.device)
+            fakes, scores = [], []
+            for _ in range(passes):
+                noise = torch.randn((B, 512), generator=gen).to(self.device)
+                logits = self.g.build_generator(images, False, noise)
+                K.argmax_rows(logits, toks.view(-1))
+                d = self.d.build_discriminator(logits, images, False)
+                fakes.append(toks.cpu().numpy().copy())
+                scores.append(d.mean(dim=1).reshape(-1).cpu().numpy())
+            fake, score = np.concatenate(fakes)[:n_samples], np.concatenate(scores)[:n_samples]
+            order = score.argsort()
+            real = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+            r50.append(self._recall(fake[order[:50]], real, 50.0))
+            r100.append(self._recall(fake[order[:100]], real, 100.0))
+        res = (float(np.mean(r50)), float(np.mean(r100)))
+        if self.rank == 0 and out_path:
+            with open(out_path, "w") as f:
+                f.write("{}\n{}".format(*res))
+        return res
 
     def sample_triples(self, images, noise=None):
         """tf.argmax(fake_inputs, -1) -> words (train.py:269-275), with the trained weights."""
