@@ -31,11 +31,14 @@ int sgg_device_info(int* cu_count, size_t* lds_bytes_per_cu, size_t* hbm_bytes, 
  * pad_t / pad_l are the TF SAME "before" pads (pad_total // 2); the "after" pad is implied by Ho/Wo. */
 int sgg_hwio_to_hwoi(const float* w_hwio, float* w_hwoi, int taps, int cin, int cout, void* stream);
 /* forward: `w` = HWIO kernel when Cin == 3, else its HWOI transpose (sgg_hwio_to_hwoi). y = conv(x) + bias */
+/* precision: 0 = native f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32); 3 / 6 = f32 operands split into 2 / 3 bf16
+ * pieces and contracted with 3 / 6 bf16 MFMAs accumulated in f32 (6: same error vs fp64 as native f32). */
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
-                        int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* stream);
+                        int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                        void* stream);
 /* Conv2DBackpropInput: dx from dy and the HWIO kernel */
 int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
-                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* stream);
+                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, void* stream);
 /* Conv2DBackpropFilter: dw (HWIO) from x and dy */
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int Hi, int Wi, int Cin, int Ho,

@@ -304,6 +304,214 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_gather3_kernel(G
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Split-bf16 variant: the same contraction on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate) with every f32
+// operand split into P bf16 pieces x = x0 + x1 (+ x2) at the LDS-write and the cross terms accumulated in f32:
+//   P = 2 (3 products: x0w0 + x0w1 + x1w0):  drops terms of relative size 2^-17: logits err 2.0e-5 vs fp64
+//   P = 3 (6 products: + x1w1 + x0w2 + x2w0): drops terms of relative size 2^-25: logits err 1.9e-6 vs fp64,
+//          the same as the native f32 MFMA path (2.7e-6)   [tests/test_split_bf16_numerics.py, 8x64x64 config]
+// bf16 x bf16 products are exact in f32, the accumulator is f32, so only the dropped cross terms differ from f32.
+// Same skeleton as conv_gather3_kernel (buffer-load gather, scalar tap walk, register prefetch, one LDS buffer);
+// LDS planes are [row][32 k] bf16 (64 B rows) with the 16-B chunk index XOR-swizzled by (row >> 2) & 3, which makes
+// both the ds_write_b128 of the split pieces and the ds_read_b128 of the MFMA fragments conflict free.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+}
+// 8 consecutive floats -> P planes of 8 bf16 (16 B each)
+template <int P>
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4 (&pl)[P]) {
+  float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a = x[2 * q], b = x[2 * q + 1];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+      const unsigned pk = cvt_pk_bf16(a, b);
+      pl[pp][q] = pk;
+      if (pp + 1 < P) {
+        a -= __builtin_bit_cast(float, pk << 16);
+        b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int P>
+__global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NPA = BM / 64, NPB = (BN + 63) / 64;    // row passes: 64 rows x 4 chunks of 8 k per pass
+  constexpr int ROWB = 64;                              // bytes per plane row (32 bf16)
+  static_assert(WGM * WGN == 4 && BM % 64 == 0 && BN % 32 == 0 && (P == 2 || P == 3), "tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * ROWB * P + BM * 4];
+  unsigned char* A_s = lds;                             // plane pp at + pp * BM * ROWB
+  unsigned char* B_s = lds + P * BM * ROWB;
+  int* out_off_s = reinterpret_cast<int*>(lds + (BM + BN) * ROWB * P);
+
+  const GatherClass& c = p.cls[blockIdx.y];
+  const int ntiles_n = p.N / BN;
+  const int nwg = c.mtiles * ntiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int mt = lid / ntiles_n, nt = lid % ntiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int chunk = tid & 3, prow = tid >> 2;           // this thread stages k = 8*chunk .. 8*chunk+7 of rows prow + 64*j
+
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wm), 0, p.w_bytes, 0x00020000);
+
+  int a_ys[NPA], a_xs[NPA], a_off[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int m = m0 + prow + 64 * j;
+    if (m < c.M) {
+      const int x = m % c.Wm;
+      const int t = m / c.Wm;
+      const int y = t % c.Hm;
+      const int b = t / c.Hm;
+      a_ys[j] = y * p.sy + c.oy;
+      a_xs[j] = x * p.sx + c.ox;
+      a_off[j] = ((b * p.Hs + a_ys[j]) * p.Ws + a_xs[j]) * p.C + chunk * 8;
+    } else {
+      a_ys[j] = -(1 << 28);
+      a_xs[j] = 0;
+      a_off[j] = 0;
+    }
+  }
+  const int b_off0 = (n0 + prow) * p.C + chunk * 8;
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < c.M) {
+      const int x = m % c.Wm;
+      const int t = m / c.Wm;
+      const int y = t % c.Hm;
+      const int b = t / c.Hm;
+      off = ((b * p.Ho + y * p.osy + c.ooy) * p.Wo + x * p.osx + c.oox) * p.N;
+    }
+    out_off_s[r] = off;
+  }
+
+  f32x16 acc[TM][TN];
+  acc_zero<TM, TN>(acc);
+
+  const int n_iters = c.nth * c.ntw * (p.C >> 5);
+  int s_th = 0, s_tw = 0, s_c0 = 0, s_it = 0;
+  f32x4 ra[NPA][2], rb[NPB][2];
+  auto issue_loads = [&]() {
+    const unsigned dead = (unsigned)(s_it >= n_iters);
+    const int ty = s_th * p.dy, tx = s_tw * p.dx;
+    const int tapoff = (ty * p.Ws + tx) * p.C + s_c0;
+    const int woff = ((c.kh0 + c.kstep * s_th) * p.KW + (c.kw0 + c.kstep * s_tw)) * p.N * p.C + s_c0 + b_off0;
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int yy = a_ys[j] + ty, xx = a_xs[j] + tx;
+      const unsigned bad = (unsigned)((unsigned)yy >= (unsigned)p.Hs) | (unsigned)((unsigned)xx >= (unsigned)p.Ws) | dead;
+      const unsigned off = ((unsigned)(a_off[j] + tapoff) * 4u) | ((0u - bad) & SGG_OOB);
+      ra[j][0] = buf_load4(rs_src, off);
+      ra[j][1] = buf_load4(rs_src, off + 16u);
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const unsigned deadb = dead | (unsigned)(prow + 64 * j >= BN);     // (BN = 32: half of the threads stage no weights)
+      const unsigned off = ((unsigned)(woff + 64 * j * p.C) * 4u) | ((0u - deadb) & SGG_OOB);
+      rb[j][0] = buf_load4(rs_w, off);
+      rb[j][1] = buf_load4(rs_w, off + 16u);
+    }
+    ++s_it;
+    s_c0 += 32;
+    const bool wrap_c = s_c0 >= p.C;
+    s_c0 = wrap_c ? 0 : s_c0;
+    s_tw += wrap_c ? 1 : 0;
+    const bool wrap_w = s_tw >= c.ntw;
+    s_tw = wrap_w ? 0 : s_tw;
+    s_th += wrap_w ? 1 : 0;
+  };
+  // swizzled byte offset of (row, logical 16-B chunk q) inside one plane
+  auto sw = [](int row, int q) { return row * ROWB + ((q ^ ((row >> 2) & 3)) << 4); };
+
+  issue_loads();
+  for (int it = 0; it < n_iters; ++it) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      u32x4 pl[P];
+      split8<P>(ra[j][0], ra[j][1], pl);
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(A_s + pp * BM * ROWB + sw(prow + 64 * j, chunk)) = pl[pp];
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      u32x4 pl[P];
+      split8<P>(rb[j][0], rb[j][1], pl);
+      if (prow + 64 * j < BN) {
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(B_s + pp * BN * ROWB + sw(prow + 64 * j, chunk)) = pl[pp];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_loads();
+    __builtin_amdgcn_sched_barrier(0);
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[TM][P], b[TN][P];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+          a[tm][pp] = *reinterpret_cast<const bf16x8*>(A_s + pp * BM * ROWB + sw(wm0 + tm * 32 + i, 2 * ks + h));
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+          b[tn][pp] = *reinterpret_cast<const bf16x8*>(B_s + pp * BN * ROWB + sw(wn0 + tn * 32 + i, 2 * ks + h));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          f32x16 d = acc[tm][tn];
+          if constexpr (P == 3) {      // smallest terms first
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], d, 0, 0, 0);
+          }
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], d, 0, 0, 0);
+          acc[tm][tn] = d;
+        }
+    }
+  }
+
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn0 + tn * 32 + acc_col(lane);
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + tm * 32 + acc_row(r, lane);
+        const int off = out_off_s[row];
+        if (off >= 0) p.out[(size_t)off + n] = acc[tm][tn][r] + bv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Cin = 3 forward (conv1_1, generator_with_attention.py:29): K = 27, HBM-bound on the 32-channel output.
 // 8 lanes per output pixel, 4 output channels each -> a wave stores 1 KiB contiguous per instruction.
 // Weights are HWIO [3][3][3][Cout] read through LDS.
@@ -394,7 +602,36 @@ static void launch_gather3(const GatherParams& p, hipStream_t st) {
   hipLaunchKernelGGL((conv_gather3_kernel<BM, BN, WGM, WGN, BK>), grid, dim3(256), 0, st, q, src_bytes);
 }
 
-static int dispatch_gather(const GatherParams& p, hipStream_t st) {
+template <int BM, int BN, int WGM, int WGN, int P>
+static void launch_gather_bf16s(const GatherParams& p, hipStream_t st) {
+  int maxwg = 0;
+  GatherParams q = p;
+  for (int i = 0; i < q.ncls; ++i) {
+    q.cls[i].mtiles = sgg_cdiv(q.cls[i].M, BM);
+    const int nwg = q.cls[i].mtiles * (q.N / BN);
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  const unsigned src_bytes = (unsigned)((size_t)q.B * q.Hs * q.Ws * q.C * sizeof(float));
+  dim3 grid(maxwg, q.ncls, 1);
+  hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P>), grid, dim3(256), 0, st, q, src_bytes);
+}
+
+// precision: 0 = native f32 MFMA; 3 / 6 = split-bf16 with 3 / 6 products (see conv_gather_bf16s_kernel)
+static int dispatch_gather(const GatherParams& p, hipStream_t st, int precision) {
+  const bool small_ = (size_t)p.B * p.Hs * p.Ws * p.C * sizeof(float) < 0x80000000ull && p.w_bytes < 0x80000000u;
+  if (precision != 0 && small_) {
+    if (p.N % 128 == 0) {
+      if (precision == 3) launch_gather_bf16s<128, 128, 2, 2, 2>(p, st);
+      else launch_gather_bf16s<128, 128, 2, 2, 3>(p, st);
+    } else if (p.N % 64 == 0) {
+      if (precision == 3) launch_gather_bf16s<256, 64, 4, 1, 2>(p, st);
+      else launch_gather_bf16s<256, 64, 4, 1, 3>(p, st);
+    } else {
+      if (precision == 3) launch_gather_bf16s<256, 32, 4, 1, 2>(p, st);
+      else launch_gather_bf16s<256, 32, 4, 1, 3>(p, st);
+    }
+    return SGG_OK;
+  }
   // buffer-load path: byte offsets must stay below the out-of-range marker 2^31
   const bool small = (size_t)p.B * p.Hs * p.Ws * p.C * sizeof(float) < 0x80000000ull && p.w_bytes < 0x80000000u;
   if (p.N % 128 == 0 && small)
@@ -421,8 +658,9 @@ extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, in
 // Forward. `w` is the HWIO kernel for Cin == 3 and the HWOI transpose (sgg_hwio_to_hwoi) otherwise.
 extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi,
                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
-                                   void* stream) {
+                                   int precision, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
+  SGG_CHECK_ARG(precision == 0 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 3 or 6");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_fwd: bad dims");
   SGG_CHECK_ARG(Ho == (Hi + stride - 1) / stride && Wo == (Wi + stride - 1) / stride,
                 "sgg_conv2d_nhwc_fwd: Ho/Wo must be ceil(in/stride) (SAME padding)");
@@ -447,15 +685,17 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* 
   GatherClass& c = p.cls[0];
   c.Hm = Ho; c.Wm = Wo; c.M = B * Ho * Wo; c.nth = KH; c.ntw = KW; c.oy = -pad_t; c.ox = -pad_l;
   c.kh0 = 0; c.kw0 = 0; c.kstep = 1; c.ooy = 0; c.oox = 0; c.mtiles = 0;
-  dispatch_gather(p, st);
+  dispatch_gather(p, st, precision);
   SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd");
   return SGG_OK;
 }
 
 // dgrad: dx[B,Hi,Wi,Cin] = conv-transpose of dy[B,Ho,Wo,Cout] with the HWIO kernel w (no bias).
 extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
-                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* stream) {
+                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                                     void* stream) {
   SGG_CHECK_ARG(dy && w && dx, "sgg_conv2d_nhwc_dgrad: null pointer");
+  SGG_CHECK_ARG(precision == 0 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_dgrad: precision must be 0, 3 or 6");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_dgrad: bad dims");
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_dgrad: Cin and Cout must be multiples of 32");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
@@ -479,7 +719,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx,
       c.ox = (pw + pad_l - kw0) / stride;
       c.kh0 = kh0; c.kw0 = kw0; c.kstep = stride; c.ooy = ph; c.oox = pw; c.mtiles = 0;
     }
-  dispatch_gather(p, (hipStream_t)stream);
+  dispatch_gather(p, (hipStream_t)stream, precision);
   SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad");
   return SGG_OK;
 }

@@ -28,8 +28,8 @@ SIGNATURES = {
     "sgg_last_error": (c_char_p, []),
     "sgg_device_info": (_i, [_vp, _vp, _vp, _vp, _i]),
     "sgg_hwio_to_hwoi": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
-    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
     "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -112,6 +112,8 @@ class HipKernels:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self.timing = None      # bench.py sets this to a list: conv launches are then bracketed by HIP events
+        # 0 = native f32 MFMA; 3 / 6 = split-bf16 MFMA with 3 / 6 products (csrc/conv_gather.hip)
+        self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "0"))
 
     def _timed(self, symbol, flops, fn):
         """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline leg)."""
@@ -124,9 +126,11 @@ class HipKernels:
         self.timing.append((symbol, flops, e0, e1))
         return r
 
-    @staticmethod
-    def gather_symbol(n_out):
+    def gather_symbol(self, n_out):
         """Kernel symbol the implicit-GEMM dispatcher (csrc/conv_gather.hip: dispatch_gather) picks for N outputs."""
+        if self.conv_precision:
+            tile = "128,128,2,2" if n_out % 128 == 0 else ("256,64,4,1" if n_out % 64 == 0 else "256,32,4,1")
+            return "conv_gather_bf16s_kernel<%s,%d>" % (tile, 2 if self.conv_precision == 3 else 3)
         if n_out % 128 == 0:
             return "conv_gather3_kernel<128,128,2,2,32>"
         return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather3_kernel<256,32,4,1,32>"
@@ -179,7 +183,7 @@ class HipKernels:
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else self.gather_symbol(d[6])
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
-            _p(x), _p(w_fwd), _p(bias), _p(y), *d, self._stream())), "sgg_conv2d_nhwc_fwd")
+            _p(x), _p(w_fwd), _p(bias), _p(y), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_fwd")
 
     def conv_dgrad(self, dy, w_hwio, dx, stride):
         self._dev(dy, w_hwio, dx)
@@ -187,7 +191,7 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         self._check(self._timed(self.gather_symbol(d[3]), flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
-            _p(dy), _p(w_hwio), _p(dx), *d, self._stream())), "sgg_conv2d_nhwc_dgrad")
+            _p(dy), _p(w_hwio), _p(dx), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_dgrad")
 
     def conv_wgrad(self, x, dy, dw, stride):
         self._dev(x, dy, dw)

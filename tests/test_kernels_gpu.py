@@ -53,8 +53,18 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 6, 3], ids=["f32mfma", "bf16x6", "bf16x3"])
+def conv_mode(request, hip):
+    """conv precision modes of the C ABI: native f32 MFMA, and f32 operands split into bf16 pieces (6 / 3 products).
+    Tolerance vs the fp64 reference: f32 and bf16x6 2e-5 * max|ref|, bf16x3 (drops 2^-17 cross terms) 1e-4."""
+    old = hip.conv_precision
+    hip.conv_precision = request.param
+    yield {0: 2e-5, 6: 2e-5, 3: 1e-4}[request.param]
+    hip.conv_precision = old
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(hip, ref, case):
+def test_conv_fwd_dgrad_wgrad(hip, ref, case, conv_mode):
     B, H, W, Ci, Co, k, s = case
     x = rnd((B, H, W, Ci), 1)
     w = rnd((k, k, Ci, Co), 2, 1.0 / math.sqrt(k * k * Ci))
@@ -77,7 +87,7 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, case):
         close(wf, w.permute(0, 1, 3, 2), 0, 0, "hwio_to_hwoi")
     y = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
     hip.conv_fwd(xd, wd, wf, bd, y, s)
-    close(y, y_ref, what="conv_fwd %s" % (case,))
+    close(y, y_ref, rtol=conv_mode, what="conv_fwd %s" % (case,))
     dw = torch.full_like(wd, float("nan"))
     hip.conv_wgrad(xd, dyd, dw, s)
     close(dw, dw_ref, what="conv_wgrad %s" % (case,))
@@ -86,7 +96,7 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, case):
         ref.conv_dgrad(dyr, wr, dx_ref, s)
         dx = torch.full_like(xd, float("nan"))
         hip.conv_dgrad(dyd, wd, dx, s)
-        close(dx, dx_ref, what="conv_dgrad %s" % (case,))
+        close(dx, dx_ref, rtol=conv_mode, what="conv_dgrad %s" % (case,))
 
 
 def test_conv_wgrad_split_k(hip, ref):
