@@ -23,6 +23,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip table: Peak FP32 (matrix)
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # same table: Peak BF16 MFMA, dense
+DTYPE_NAME = {0: "f32 (native f32 MFMA)",
+              6: "f32 (conv operands split into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate; error vs fp64 = native f32)",
+              3: "f32 storage, conv operands split into 2 bf16 pieces (3 bf16 MFMAs per product, f32 accumulate)"}
 
 
 def conv_flops_per_step(B, S):
@@ -89,6 +93,9 @@ def main():
     ap.add_argument("--critic-iters", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 3, 6],
+                    help="conv contraction: 6 = f32 via 6-product bf16 split (default, f32-equivalent error), "
+                         "0 = native f32 MFMA, 3 = 3-product bf16 split (within the stated 1e-4 tolerance)")
     args = ap.parse_args()
 
     import sgg_amd  # noqa: F401
@@ -103,6 +110,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda:%d" % local)
     K = HipKernels(dev)
+    if args.conv_precision is not None:
+        K.conv_precision = args.conv_precision
     B, S, V, CI = args.batch, args.size, args.vocab, args.critic_iters
     reducer = dpmod.GradReducer() if world > 1 else None
     gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer)
@@ -145,7 +154,7 @@ def main():
         out = {
             "metric": "triples/sec (G+D step)", "value": value, "unit": "triples/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_NAME[K.conv_precision], "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: batch %d per GPU, %dx%d synthetic images, vocab %d, 3-token "
                                    "triples, 1 critic update + 1 generator update per step (WGAN-GP lambda=10, TF-Adam)"
                                    % (B, S, S, V), "global_batch": B * world, "critic_iters": CI,
@@ -168,8 +177,13 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(dom)
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            nprod = K.conv_precision if K.conv_precision else 1
+            peak = MFMA_BF16_PEAK_TFLOPS / nprod if K.conv_precision else MFMA_F32_PEAK_TFLOPS
+            note = ("dense bf16 MFMA peak %.0f TFLOP/s / %d MFMA products per algorithmic f32 product" % (MFMA_BF16_PEAK_TFLOPS, nprod)
+                    if K.conv_precision else "f32 matrix peak")
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": peak, "peak_note": note,
+                               "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic,
+                               "mfma_tflops_issued": nprod * fl / sec / 1e12, "vs_native_f32_mfma_peak": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                "launches": n, "avg_launch_ms": 1e3 * sec / n, "flop_per_launch": fl / n,
                                "share_of_step_time": sec / dt}
             out["kernel_time_s"] = {s: round(v[2], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][2])}

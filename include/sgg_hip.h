@@ -42,8 +42,8 @@ int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, float* dx, int B
 /* Conv2DBackpropFilter: dw (HWIO) from x and dy */
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int Hi, int Wi, int Cin, int Ho,
-                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- tf.contrib.layers.layer_norm(activation_fn=tf.nn.elu) over (H,W,C) per sample ------------------------
  * generator_with_attention.py:30..66 / discriminator_with_attention.py:30..66.  C: power of two in [4,1024].

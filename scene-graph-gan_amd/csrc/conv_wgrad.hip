@@ -9,6 +9,74 @@
 // slabs in a fixed order (deterministic, no atomics).
 #include "mma_f32.h"
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 floats -> P bf16 pieces (x = x0 + x1 (+ x2)), each packed as 8 bf16 (see conv_gather_bf16s_kernel)
+template <int P>
+__device__ __forceinline__ void split8_regs(const float (&x)[8], bf16x8 (&out)[P]) {
+  u32x4 pl[P];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a = x[2 * q], b = x[2 * q + 1];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+      const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));
+      pl[pp][q] = pk;
+      if (pp + 1 < P) {
+        a -= __builtin_bit_cast(float, pk << 16);
+        b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int pp = 0; pp < P; ++pp) out[pp] = __builtin_bit_cast(bf16x8, pl[pp]);
+}
+
+// Split-bf16 contraction of MC tiles (f32 in LDS, [pixel][channel]): each wave gathers its fragments with the pixel
+// (= k) index running down the LDS rows (ds_read_b32, conflict free), splits them in registers and issues
+// 3 (P = 2) or 6 (P = 3) v_mfma_f32_32x32x16_bf16 per tile and 16-pixel step.  k_count must be a multiple of 16.
+template <int TM, int TN, int P>
+__device__ __forceinline__ void mma_slab_mc_mc_split(const float* __restrict__ A_s, int lda_s, const float* __restrict__ B_s,
+                                                     int ldb_s, int wm0, int wn0, int k_begin, int k_count, int lane,
+                                                     f32x16 (&acc)[TM][TN]) {
+  const int i = lane & 31, h = lane >> 5;
+  for (int k = k_begin; k < k_begin + k_count; k += 16) {
+    bf16x8 a[TM][P], b[TN][P];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = A_s[(k + 8 * h + j) * lda_s + wm0 + tm * 32 + i];
+      split8_regs<P>(x, a[tm]);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = B_s[(k + 8 * h + j) * ldb_s + wn0 + tn * 32 + i];
+      split8_regs<P>(x, b[tn]);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        f32x16 d = acc[tm][tn];
+        if constexpr (P == 3) {
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], d, 0, 0, 0);
+        }
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], d, 0, 0, 0);
+        acc[tm][tn] = d;
+      }
+  }
+}
+
 struct WgradParams {
   const float* x;
   const float* dy;
@@ -19,7 +87,7 @@ struct WgradParams {
   unsigned x_bytes, dy_bytes;    // buffer descriptor bounds
 };
 
-template <int BMC, int BNC, int WM, int WN>
+template <int BMC, int BNC, int WM, int WN, int P>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   constexpr int WGM = BMC / WM, WGN = BNC / WN, WGK = 4 / (WGM * WGN);
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -94,7 +162,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     __builtin_amdgcn_s_barrier();
     issue_loads(pix0 + 32);                               // past pix_end: zeros, no traffic
     __builtin_amdgcn_sched_barrier(0);
-    mma_slab_mc_mc<TM, TN>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
+    if constexpr (P == 0) {
+      mma_slab_mc_mc<TM, TN>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
+    } else if constexpr (KROWS >= 16) {
+      mma_slab_mc_mc_split<TM, TN, P>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
+    } else {
+      // 4-way k-split tiles (32x32 channels): a bf16 MFMA step is 16 pixels deep, so two of the four waves take
+      // one step each and the other two only help staging
+      if (wk < 2) mma_slab_mc_mc_split<TM, TN, P>(A_s, BMC, B_s, BNC, wm0, wn0, wk * 16, 16, lane, acc);
+    }
   }
 
   if constexpr (WGK > 1) {
@@ -240,9 +316,10 @@ extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, i
 }
 
 extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,
-                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   SGG_CHECK_ARG(x && dy && dw, "sgg_conv2d_nhwc_wgrad: null pointer");
+  SGG_CHECK_ARG(precision == 0 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_wgrad: precision must be 0, 3 or 6");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_wgrad: bad dims");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
                 "sgg_conv2d_nhwc_wgrad: tensor exceeds 2^31 elements");
@@ -283,8 +360,12 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
                     (size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull && (size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull,
                 "sgg_conv2d_nhwc_wgrad: tensor too large for the 32-bit offset path");
   dim3 grid(pl.tiles, KH * KW, pl.nsplit);
-#define SGG_WG(BMC, BNC, WM, WN) \
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN>), grid, dim3(256), 0, st, p)
+#define SGG_WG(BMC, BNC, WM, WN)                                                                        \
+  do {                                                                                                \
+    if (precision == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 0>), grid, dim3(256), 0, st, p);      \
+    else if (precision == 3) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 2>), grid, dim3(256), 0, st, p); \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 3>), grid, dim3(256), 0, st, p);                     \
+  } while (0)
   if (pl.bmc == 32 && pl.bnc == 32) SGG_WG(32, 32, 32, 32);
   else if (pl.bmc == 32 && pl.bnc == 64) SGG_WG(32, 64, 32, 32);
   else if (pl.bmc == 64 && pl.bnc == 32) SGG_WG(64, 32, 32, 32);

@@ -31,7 +31,7 @@ SIGNATURES = {
     "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
-    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
+    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
     "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 9 + [_i] * 3 + [_vp, _sz, _vp]),
@@ -112,8 +112,13 @@ class HipKernels:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self.timing = None      # bench.py sets this to a list: conv launches are then bracketed by HIP events
-        # 0 = native f32 MFMA; 3 / 6 = split-bf16 MFMA with 3 / 6 products (csrc/conv_gather.hip)
-        self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "0"))
+        # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
+        #   6 (default) f32 operands split into three bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate: the error
+        #               against fp64 equals the native f32 path's (dropped terms are 2^-27 relative), 1.35-1.5x faster;
+        #   0           native f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 fmaf chain);
+        #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance), fastest.
+        self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "6"))
+        assert self.conv_precision in (0, 3, 6)
 
     def _timed(self, symbol, flops, fn):
         """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline leg)."""
@@ -201,7 +206,7 @@ class HipKernels:
         ws = self.workspace(need)
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         self._check(self._timed("conv_wgrad(call: wgrad kernel + slab reduce)", flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
-            _p(x), _p(dy), _p(dw), *d, _p(ws), ws.numel(), self._stream())), "sgg_conv2d_nhwc_wgrad")
+            _p(x), _p(dy), _p(dw), *d, self.conv_precision, _p(ws), ws.numel(), self._stream())), "sgg_conv2d_nhwc_wgrad")
 
     def ln_elu_fwd(self, y, gamma, beta, a, stats):
         self._dev(y, gamma, beta, a, stats)

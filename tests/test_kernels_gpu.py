@@ -90,7 +90,7 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, case, conv_mode):
     close(y, y_ref, rtol=conv_mode, what="conv_fwd %s" % (case,))
     dw = torch.full_like(wd, float("nan"))
     hip.conv_wgrad(xd, dyd, dw, s)
-    close(dw, dw_ref, what="conv_wgrad %s" % (case,))
+    close(dw, dw_ref, rtol=conv_mode, what="conv_wgrad %s" % (case,))
     if Ci != 3:
         dx_ref = torch.empty_like(xr)
         ref.conv_dgrad(dyr, wr, dx_ref, s)
