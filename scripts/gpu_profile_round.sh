@@ -12,5 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 > $O/bench_under_rocprof.json 2> $O/stats.err
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-rows 0 --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-rows 0 --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
+cd $R
+timeout -k 10 300 python bench.py --conv-precision 0 --cpu-rows 0 > $O/bench_precision0_native_f32_mfma.json 2>/dev/null
+timeout -k 10 300 python bench.py --conv-precision 3 --cpu-rows 0 > $O/bench_precision3_bf16x3.json 2>/dev/null
 rm -f $O/stats/k_kernel_trace.csv     # large; the per-kernel stats summary is what gets committed
 ls -R $O | head -40

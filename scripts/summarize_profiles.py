@@ -7,7 +7,8 @@ src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), os.path.join(dst, "%s_rocprofv3_kernel_stats.csv" % tag))
-for f in ("bench.json", "bench_under_rocprof.json", "pytest_gpu.log"):
+for f in ("bench.json", "bench_under_rocprof.json", "pytest_gpu.log", "bench_precision0_native_f32_mfma.json",
+          "bench_precision3_bf16x3.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
 
