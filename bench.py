@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--critic-iters", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--overlap-streams", action="store_true", help="run the two encoders' forwards on two HIP streams (+3 %%)")
     ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 3, 6],
                     help="conv contraction: 6 = f32 via 6-product bf16 split (default, f32-equivalent error), "
                          "0 = native f32 MFMA, 3 = 3-product bf16 split (within the stated 1e-4 tolerance)")
@@ -114,7 +115,8 @@ def main():
         K.conv_precision = args.conv_precision
     B, S, V, CI = args.batch, args.size, args.vocab, args.critic_iters
     reducer = dpmod.GradReducer() if world > 1 else None
-    gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer)
+    gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer,
+                 overlap_streams=args.overlap_streams)
     total_steps = args.warmup + args.steps
     images, labels, noises, alphas = synth_inputs(B * world, S, V, total_steps * (CI + 1), rank, world, dev)
 

@@ -110,7 +110,7 @@ class HipKernels:
         if not torch.cuda.is_available():
             raise SggError("no HIP device visible: the scene-graph-gan_amd product path has no CPU fallback")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._ws_by_stream = {}
         self.timing = None      # bench.py sets this to a list: conv launches are then bracketed by HIP events
         # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
         #   6 (default) f32 operands split into three bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate: the error
@@ -154,9 +154,13 @@ class HipKernels:
                 raise SggError("tensor is not on a HIP device (no CPU fallback in the product path)")
 
     def workspace(self, nbytes: int):
-        if self._ws.numel() < nbytes:
-            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Scratch buffer of the CURRENT stream (kernels on different streams may run concurrently)."""
+        sid = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws_by_stream.get(sid)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes * 1.25) + 256, 1 << 20), dtype=torch.uint8, device=self.device)
+            self._ws_by_stream[sid] = ws
+        return ws
 
     def device_info(self):
         cu, lds, hbm = c_int(0), c_size_t(0), c_size_t(0)

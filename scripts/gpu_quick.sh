@@ -1,7 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-for prec in 6 3; do
-for args in "64 112 128 128 3 1 5 fwd" "64 56 256 512 5 2 5 fwd" "64 28 512 512 5 2 5 fwd"; do
-  SGG_CONV_PRECISION=$prec timeout -k 10 120 python scripts/prof_conv.py $args 2>/dev/null
-done
-done
+timeout -k 10 300 python -m pytest tests/test_step_gpu.py tests/test_golden.py tests/test_api_gpu.py -m gpu -q 2>&1 | tail -2
+bash scripts/gpu_bench_short.sh
+SGG_CONV_PRECISION=3 bash scripts/gpu_bench_short.sh
