@@ -33,11 +33,14 @@ int sgg_hwio_to_hwoi(const float* w_hwio, float* w_hwoi, int taps, int cin, int 
 /* forward: `w` = HWIO kernel when Cin == 3, else its HWOI transpose (sgg_hwio_to_hwoi). y = conv(x) + bias */
 /* precision: 0 = native f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32); 3 / 6 = f32 operands split into 2 / 3 bf16
  * pieces and contracted with 3 / 6 bf16 MFMAs accumulated in f32 (6: same error vs fp64 as native f32). */
-int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
+/* w_split (optional, may be NULL): the same weights pre-split by sgg_split_bf16 into precision/2 bf16 planes [P][n];
+ * saves the per-workgroup split of the weight operand in the split-bf16 modes. */
+int sgg_split_bf16(const float* in, void* out, long long n, int precision, void* stream);
+int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
                         void* stream);
 /* Conv2DBackpropInput: dx from dy and the HWIO kernel */
-int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
+int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, void* stream);
 /* Conv2DBackpropFilter: dw (HWIO) from x and dy */
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);

@@ -30,6 +30,7 @@ struct GatherParams {
   const float* wm;
   const float* bias;  // may be null
   float* out;
+  const void* w_split;  // optional: the weights pre-split into P bf16 planes [P][taps*N*C] (sgg_split_bf16), else null
   int B, Hs, Ws, C;  // source grid, channels (= contraction length per tap), C % 32 == 0
   int N;             // output channels, N % 32 == 0
   int Ho, Wo;        // full output grid
@@ -341,7 +342,7 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4 (
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int P>
+template <int BM, int BN, int WGM, int WGN, int P, bool WS>
 __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -367,7 +368,11 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
   const int chunk = tid & 3, prow = tid >> 2;           // this thread stages k = 8*chunk .. 8*chunk+7 of rows prow + 64*j
 
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wm), 0, p.w_bytes, 0x00020000);
+  // WS: weights arrive pre-split (P bf16 planes, written once per optimiser step) - no split VALU for the B operand
+  const __amdgpu_buffer_rsrc_t rs_w =
+      WS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_split), 0, (p.w_bytes / 2) * P, 0x00020000)
+         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wm), 0, p.w_bytes, 0x00020000);
+  const unsigned w_plane_bytes = p.w_bytes / 2;
 
   int a_ys[NPA], a_xs[NPA], a_off[NPA];
 #pragma unroll
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
 
   const int n_iters = c.nth * c.ntw * (p.C >> 5);
   int s_th = 0, s_tw = 0, s_c0 = 0, s_it = 0;
-  f32x4 ra[NPA][2], rb[NPB][2];
+  f32x4 ra[NPA][2], rb[NPB][WS ? P : 2];
   auto issue_loads = [&]() {
     const unsigned dead = (unsigned)(s_it >= n_iters);
     const int ty = s_th * p.dy, tx = s_tw * p.dx;
@@ -423,9 +428,15 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
       const unsigned deadb = dead | (unsigned)(prow + 64 * j >= BN);     // (BN = 32: half of the threads stage no weights)
-      const unsigned off = ((unsigned)(woff + 64 * j * p.C) * 4u) | ((0u - deadb) & SGG_OOB);
-      rb[j][0] = buf_load4(rs_w, off);
-      rb[j][1] = buf_load4(rs_w, off + 16u);
+      if constexpr (WS) {
+        const unsigned off = ((unsigned)(woff + 64 * j * p.C) * 2u) | ((0u - deadb) & SGG_OOB);
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) rb[j][pp] = buf_load4(rs_w, off + pp * w_plane_bytes);
+      } else {
+        const unsigned off = ((unsigned)(woff + 64 * j * p.C) * 4u) | ((0u - deadb) & SGG_OOB);
+        rb[j][0] = buf_load4(rs_w, off);
+        rb[j][1] = buf_load4(rs_w, off + 16u);
+      }
     }
     ++s_it;
     s_c0 += 32;
@@ -453,7 +464,12 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
       u32x4 pl[P];
-      split8<P>(rb[j][0], rb[j][1], pl);
+      if constexpr (WS) {
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) pl[pp] = __builtin_bit_cast(u32x4, rb[j][pp]);
+      } else {
+        split8<P>(rb[j][0], rb[j][1], pl);
+      }
       if (prow + 64 * j < BN) {
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(B_s + pp * BN * ROWB + sw(prow + 64 * j, chunk)) = pl[pp];
@@ -613,7 +629,10 @@ static void launch_gather_bf16s(const GatherParams& p, hipStream_t st) {
   }
   const unsigned src_bytes = (unsigned)((size_t)q.B * q.Hs * q.Ws * q.C * sizeof(float));
   dim3 grid(maxwg, q.ncls, 1);
-  hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P>), grid, dim3(256), 0, st, q, src_bytes);
+  if (q.w_split && (size_t)(q.w_bytes / 2) * P < 0x80000000ull)
+    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, true>), grid, dim3(256), 0, st, q, src_bytes);
+  else
+    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, false>), grid, dim3(256), 0, st, q, src_bytes);
 }
 
 // precision: 0 = native f32 MFMA; 3 / 6 = split-bf16 with 3 / 6 products (see conv_gather_bf16s_kernel)
@@ -647,6 +666,29 @@ static int dispatch_gather(const GatherParams& p, hipStream_t st, int precision)
   return SGG_OK;
 }
 
+// f32 [n] -> P planes of bf16 [P][n] with x = x0 + x1 (+ x2), the operand format of conv_gather_bf16s_kernel<.., WS = true>
+template <int P>
+__global__ void split_bf16_kernel(const float* __restrict__ in, unsigned* __restrict__ out, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const f32x4 v0 = reinterpret_cast<const f32x4*>(in)[2 * i], v1 = reinterpret_cast<const f32x4*>(in)[2 * i + 1];
+  u32x4 pl[P];
+  split8<P>(v0, v1, pl);
+#pragma unroll
+  for (int pp = 0; pp < P; ++pp) reinterpret_cast<u32x4*>(out)[(long long)pp * n8 + i] = pl[pp];
+}
+
+extern "C" int sgg_split_bf16(const float* in, void* out, long long n, int precision, void* stream) {
+  SGG_CHECK_ARG(in && out && n > 0 && n % 8 == 0 && (precision == 3 || precision == 6), "sgg_split_bf16: bad argument");
+  const long long n8 = n / 8;
+  if (precision == 3)
+    hipLaunchKernelGGL(split_bf16_kernel<2>, dim3(sgg_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, in, (unsigned*)out, n8);
+  else
+    hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(sgg_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, in, (unsigned*)out, n8);
+  SGG_LAUNCH_CHECK("sgg_split_bf16");
+  return SGG_OK;
+}
+
 extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, int cout, void* stream) {
   SGG_CHECK_ARG(w && wt && taps > 0 && cin > 0 && cout > 0, "sgg_hwio_to_hwoi: bad argument");
   dim3 grid(sgg_cdiv(cout, 32), sgg_cdiv(cin, 32), taps);
@@ -656,7 +698,7 @@ extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, in
 }
 
 // Forward. `w` is the HWIO kernel for Cin == 3 and the HWOI transpose (sgg_hwio_to_hwoi) otherwise.
-extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi,
+extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi,
                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
                                    int precision, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
@@ -677,7 +719,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* 
   }
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_fwd: Cin and Cout must be multiples of 32 (or Cin == 3)");
   GatherParams p;
-  p.src = x; p.wm = w; p.bias = bias; p.out = y;
+  p.src = x; p.wm = w; p.bias = bias; p.out = y; p.w_split = (precision != 0) ? w_split : nullptr;
   p.B = B; p.Hs = Hi; p.Ws = Wi; p.C = Cin; p.N = Cout; p.Ho = Ho; p.Wo = Wo;
   p.sy = stride; p.sx = stride; p.dy = 1; p.dx = 1; p.osy = 1; p.osx = 1; p.KW = KW;
   p.ncls = 1;
@@ -691,7 +733,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const float* 
 }
 
 // dgrad: dx[B,Hi,Wi,Cin] = conv-transpose of dy[B,Ho,Wo,Cout] with the HWIO kernel w (no bias).
-extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
+extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
                                      void* stream) {
   SGG_CHECK_ARG(dy && w && dx, "sgg_conv2d_nhwc_dgrad: null pointer");
@@ -701,7 +743,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, float* dx,
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
                 "sgg_conv2d_nhwc_dgrad: tensor exceeds 2^31 elements");
   GatherParams p;
-  p.src = dy; p.wm = w; p.bias = nullptr; p.out = dx;
+  p.src = dy; p.wm = w; p.bias = nullptr; p.out = dx; p.w_split = (precision != 0) ? w_split : nullptr;
   p.B = B; p.Hs = Ho; p.Ws = Wo; p.C = Cout; p.N = Cin; p.Ho = Hi; p.Wo = Wi;
   p.sy = 1; p.sx = 1; p.dy = -1; p.dx = -1; p.osy = stride; p.osx = stride; p.KW = KW;
   p.ncls = stride * stride;

@@ -28,8 +28,9 @@ SIGNATURES = {
     "sgg_last_error": (c_char_p, []),
     "sgg_device_info": (_i, [_vp, _vp, _vp, _vp, _i]),
     "sgg_hwio_to_hwoi": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
-    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "sgg_split_bf16": (_i, [_vp, _vp, _ll, _i, _vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
     "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -184,7 +185,12 @@ class HipKernels:
         Wo, pl, _ = same_pads(Wi, KW, stride)
         return B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pt, pl
 
-    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride):
+    def split_bf16(self, w, out):
+        """w fp32 (n % 8 == 0) -> out int16 [P, n] bf16 planes for the current conv precision (3 -> P=2, 6 -> P=3)."""
+        self._dev(w, out)
+        self._check(self.lib.sgg_split_bf16(_p(w), _p(out), w.numel(), self.conv_precision, self._stream()), "sgg_split_bf16")
+
+    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
         self._dev(x, w_fwd, bias, y)
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
@@ -192,15 +198,15 @@ class HipKernels:
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else self.gather_symbol(d[6])
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
-            _p(x), _p(w_fwd), _p(bias), _p(y), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_fwd")
+            _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_fwd")
 
-    def conv_dgrad(self, dy, w_hwio, dx, stride):
+    def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None):
         self._dev(dy, w_hwio, dx)
         d = self._conv_dims(dx.shape, w_hwio.shape, stride)
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         self._check(self._timed(self.gather_symbol(d[3]), flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
-            _p(dy), _p(w_hwio), _p(dx), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_dgrad")
+            _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_dgrad")
 
     def conv_wgrad(self, x, dy, dw, stride):
         self._dev(x, dy, dw)

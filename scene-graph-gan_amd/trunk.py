@@ -37,6 +37,11 @@ class Trunk:
                 "y": torch.empty((B, ho, wo, cout), device=dev, dtype=dt),
             }
             lay["w_fwd"] = lay["w"] if cin == 3 else torch.empty((k, k, cout, cin), device=dev, dtype=dt)
+            # split-bf16 modes: both weight layouts pre-split into bf16 planes once per optimiser step (HIP backend only)
+            lay["ws_fwd"] = lay["ws_bwd"] = None
+            if cin != 3 and getattr(K, "conv_precision", 0) and hasattr(K, "split_bf16"):
+                lay["ws_fwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
+                lay["ws_bwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
             if has_ln:
                 lay["gamma"], lay["beta"] = p[ln_name(i) + "/gamma"], p[ln_name(i) + "/beta"]
                 lay["ggamma"], lay["gbeta"] = g[ln_name(i) + "/gamma"], g[ln_name(i) + "/beta"]
@@ -56,6 +61,10 @@ class Trunk:
         for lay in self.layers:
             if lay["cin"] != 3:
                 self.K.hwio_to_hwoi(lay["w"], lay["w_fwd"])
+                if lay["ws_fwd"] is not None and self.K.conv_precision:
+                    self.K.split_bf16(lay["w_fwd"], lay["ws_fwd"])
+                    self.K.split_bf16(lay["w"], lay["ws_bwd"])
+                    lay["ws_mode"] = self.K.conv_precision
 
     def forward(self, images):
         """images [B,S,S,3] NHWC fp32, already standardised (train.py:172) -> downsampled as ctx [B, L, 512]."""
@@ -64,7 +73,10 @@ class Trunk:
         self.images = images
         x = images
         for lay in self.layers:
-            K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
+            if lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision:
+                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], lay["ws_fwd"])
+            else:
+                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             if lay["has_ln"]:
                 K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"])
                 x = lay["a"]
@@ -90,6 +102,9 @@ class Trunk:
             numel = prev["a"].numel()
             dA = self._dA[:numel].view(prev["out_shape"])
             dYp = self._dY[:numel].view(prev["out_shape"])
-            K.conv_dgrad(dy, lay["w"], dA, lay["s"])
+            if lay["ws_bwd"] is not None and lay.get("ws_mode") == K.conv_precision:
+                K.conv_dgrad(dy, lay["w"], dA, lay["s"], lay["ws_bwd"])
+            else:
+                K.conv_dgrad(dy, lay["w"], dA, lay["s"])
             K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"])
             dy = dYp

@@ -88,6 +88,12 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, case, conv_mode):
     y = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
     hip.conv_fwd(xd, wd, wf, bd, y, s)
     close(y, y_ref, rtol=conv_mode, what="conv_fwd %s" % (case,))
+    if hip.conv_precision and Ci != 3:      # same result with the weights pre-split into bf16 planes
+        ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+        hip.split_bf16(wf, ws)
+        y2 = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
+        hip.conv_fwd(xd, wd, wf, bd, y2, s, ws)
+        assert torch.equal(y2, y), "pre-split weights must give bit-identical outputs"
     dw = torch.full_like(wd, float("nan"))
     hip.conv_wgrad(xd, dyd, dw, s)
     close(dw, dw_ref, rtol=conv_mode, what="conv_wgrad %s" % (case,))
@@ -97,6 +103,12 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, case, conv_mode):
         dx = torch.full_like(xd, float("nan"))
         hip.conv_dgrad(dyd, wd, dx, s)
         close(dx, dx_ref, rtol=conv_mode, what="conv_dgrad %s" % (case,))
+        if hip.conv_precision:
+            ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+            hip.split_bf16(wd, ws)
+            dx2 = torch.full_like(xd, float("nan"))
+            hip.conv_dgrad(dyd, wd, dx2, s, ws)
+            assert torch.equal(dx2, dx)
 
 
 def test_conv_wgrad_split_k(hip, ref):
