@@ -88,18 +88,20 @@ struct WgradParams {
 };
 
 template <int BMC, int BNC, int WM, int WN, int P>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p) {
   constexpr int WGM = BMC / WM, WGN = BNC / WN, WGK = 4 / (WGM * WGN);
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int NPA = BMC / 32, NPB = BNC / 32;
-  constexpr int KROWS = 32 / WGK;
-  constexpr int TILE_FLOATS = 32 * (BMC + BNC);
+  // pixels per slab: a bf16 MFMA step is 16 pixels deep, so the 4-way k-split tiles (32x32 channels) take 64-pixel slabs
+  constexpr int SLAB = (P != 0 && WGK == 4) ? 64 : 32;
+  constexpr int NPA = SLAB * BMC / 1024, NPB = SLAB * BNC / 1024;
+  constexpr int KROWS = SLAB / WGK;
+  constexpr int TILE_FLOATS = SLAB * (BMC + BNC);
   constexpr int RED_FLOATS = (WGK > 1) ? 4 * TM * TN * 16 * 64 : 0;
   constexpr int LDS_FLOATS = TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS;
   static_assert(WGM * WGN * WGK == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* A_s = lds;
-  float* B_s = lds + 32 * BMC;
+  float* B_s = lds + SLAB * BMC;
 
   const int tile = blockIdx.x;
   const int ci0 = (tile / p.ntile_n) * BMC, co0 = (tile % p.ntile_n) * BNC;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   };
 
   issue_loads(pix_begin);
-  for (int pix0 = pix_begin; pix0 < pix_end; pix0 += 32) {
+  for (int pix0 = pix_begin; pix0 < pix_end; pix0 += SLAB) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -160,16 +162,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     for (int j = 0; j < NPB; ++j) *reinterpret_cast<f32x4*>(B_s + (tid + 256 * j) * 4) = rb[j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue_loads(pix0 + 32);                               // past pix_end: zeros, no traffic
+    issue_loads(pix0 + SLAB);                             // past pix_end: zeros, no traffic
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (P == 0) {
       mma_slab_mc_mc<TM, TN>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
-    } else if constexpr (KROWS >= 16) {
-      mma_slab_mc_mc_split<TM, TN, P>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
     } else {
-      // 4-way k-split tiles (32x32 channels): a bf16 MFMA step is 16 pixels deep, so two of the four waves take
-      // one step each and the other two only help staging
-      if (wk < 2) mma_slab_mc_mc_split<TM, TN, P>(A_s, BMC, B_s, BNC, wm0, wn0, wk * 16, 16, lane, acc);
+      static_assert(P == 0 || KROWS % 16 == 0, "bf16 MFMA step is 16 pixels deep");
+      mma_slab_mc_mc_split<TM, TN, P>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
     }
   }
 
@@ -374,7 +373,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   else if (pl.bmc == 128 && pl.bnc == 32) SGG_WG(128, 32, 32, 32);
   else if (pl.bmc == 64 && pl.bnc == 128) SGG_WG(64, 128, 32, 64);
   else if (pl.bmc == 128 && pl.bnc == 64) SGG_WG(128, 64, 64, 32);
-  else SGG_WG(128, 128, 64, 64);
+  else SGG_WG(128, 128, 64, 64);   // (a variant that splits once at the LDS write into a transposed bf16 image measured 5 % slower)
 #undef SGG_WG
   SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad");
   if (pl.nsplit > 1) {

@@ -361,17 +361,26 @@ __global__ __launch_bounds__(256) void lnlstm_gates_bwd_kernel(const float* __re
 // spatial mean + column sums
 // ---------------------------------------------------------------------------------------------------
 // out_c[r, :] = out_h[r, :] = mean_l ctx[r % B, l, :]   for r in [0, R)
+// grid (B, C/128): 256 threads = 32 lanes x float4 (128 channels) x 8 row groups over L
 __global__ __launch_bounds__(256) void spatial_mean_fwd_kernel(const float* __restrict__ ctx, float* __restrict__ out_c, int ldc,
                                                                float* __restrict__ out_h, int ldh, int R, int B, int L, int C) {
-  const int b = blockIdx.x;
-  const float invL = 1.f / (float)L;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int l = 0; l < L; ++l) s += ctx[((size_t)b * L + l) * C + c];
-    s *= invL;
+  __shared__ f32x4 part[8][32];
+  const int b = blockIdx.x, c = blockIdx.y * 128 + (threadIdx.x & 31) * 4, rg = threadIdx.x >> 5;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int l = rg; l < L; l += 8) s += *reinterpret_cast<const f32x4*>(ctx + ((size_t)b * L + l) * C + c);
+  part[rg][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += part[k][threadIdx.x & 31];
+    s *= 1.f / (float)L;
     for (int r = b; r < R; r += B) {
-      out_c[(size_t)r * ldc + c] = s;
-      out_h[(size_t)r * ldh + c] = s;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        out_c[(size_t)r * ldc + c + q] = s[q];
+        out_h[(size_t)r * ldh + c + q] = s[q];
+      }
     }
   }
 }
@@ -505,7 +514,9 @@ extern "C" int sgg_lnlstm_gates_bwd(const float* gates, const float* gates_dual,
 extern "C" int sgg_spatial_mean_fwd(const float* ctx, float* out_c, int ldc, float* out_h, int ldh, int R, int B, int L, int C,
                                     void* stream) {
   SGG_CHECK_ARG(ctx && out_c && out_h && R > 0 && B > 0 && R % B == 0 && L > 0 && C > 0, "sgg_spatial_mean_fwd: bad argument");
-  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ctx, out_c, ldc, out_h, ldh, R, B, L, C);
+  SGG_CHECK_ARG(C % 4 == 0, "sgg_spatial_mean_fwd: C must be a multiple of 4");
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(B, sgg_cdiv(C, 128)), dim3(256), 0, (hipStream_t)stream, ctx, out_c, ldc, out_h,
+                     ldh, R, B, L, C);
   SGG_LAUNCH_CHECK("sgg_spatial_mean_fwd");
   return SGG_OK;
 }

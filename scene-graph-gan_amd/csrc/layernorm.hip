@@ -201,16 +201,17 @@ __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __rest
   }
 }
 
-// grid = C/32 workgroups; 256 threads = 32 channels x 8 lanes over (b,g) pairs
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ sspart, const float* __restrict__ chpart,
-                                                              const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ dbias, int B, int C, int G, int HW) {
-  extern __shared__ float sm[];  // [B][2] per-sample (s1/N, s2/N), then [8][32][3] reduce
+// grid = C/32 workgroups; 1024 threads = 32 channels x 32 lanes over the samples
+#define LNF_BL 32
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ sspart, const float* __restrict__ chpart,
+                                                               const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dbias, int B, int C, int G, int HW) {
+  extern __shared__ float sm[];  // [B][2] per-sample (s1/N, s2/N), then [LNF_BL][32][3] reduce
   float* ssb = sm;
   float* redc = sm + 2 * B;
   const float invN = 1.f / ((float)HW * (float)C);
-  for (int b = threadIdx.x; b < B; b += 256) {
+  for (int b = threadIdx.x; b < B; b += 1024) {
     float a1 = 0.f, a2 = 0.f;
     for (int g = 0; g < G; ++g) {
       a1 += sspart[((size_t)b * G + g) * 2 + 0];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
   float dg = 0.f, dbt = 0.f, dbs = 0.f;
   if (c < C) {
     const float gm = gamma[c];
-    for (int b = bl; b < B; b += 8) {
+    for (int b = bl; b < B; b += LNF_BL) {
       float A = 0.f, Bc = 0.f, X = 0.f;
       for (int g = 0; g < G; ++g) {
         const float* o = chpart + ((size_t)b * G + g) * 3 * C;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
   __syncthreads();
   if (bl == 0 && c < C) {
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < LNF_BL; ++k) {
       r0 += redc[(k * 32 + cl) * 3 + 0];
       r1 += redc[(k * 32 + cl) * 3 + 1];
       r2 += redc[(k * 32 + cl) * 3 + 2];
@@ -338,8 +339,8 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
   float* chpart = sspart + (size_t)B * g.G * 2;
   hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart, g.N, C,
                      g.G, g.cpg);
-  const size_t sm = (size_t)(2 * B + 8 * 32 * 3) * sizeof(float);
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(256), sm, st, (const float*)sspart,
+  const size_t sm = (size_t)(2 * B + LNF_BL * 32 * 3) * sizeof(float);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sspart,
                      (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, HW);
   hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, (const float*)sspart, dy,
                      g.N, C, g.G, g.cpg);
