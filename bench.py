@@ -24,7 +24,10 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip table: Peak FP32 (matrix)
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # same table: Peak BF16 MFMA, dense
+MFMA_F16_PEAK_TFLOPS = 2500.0     # f16 MFMA runs at the bf16 rate (MI355X_MICROARCH.md, Matrix cores table)
 DTYPE_NAME = {0: "f32 (native f32 MFMA)",
+              2: "f32 (conv operands scaled per tensor and split into 2 fp16 pieces = 22 significant bits, 3 fp16 MFMAs per "
+                 "product, f32 accumulate; error vs fp64 = native f32)",
               6: "f32 (conv operands split into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate; error vs fp64 = native f32)",
               3: "f32 storage, conv operands split into 2 bf16 pieces (3 bf16 MFMAs per product, f32 accumulate)"}
 
@@ -94,9 +97,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap-streams", action="store_true", help="run the two encoders' forwards on two HIP streams (+3 %%)")
-    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 3, 6],
-                    help="conv contraction: 6 = f32 via 6-product bf16 split (default, f32-equivalent error), "
-                         "0 = native f32 MFMA, 3 = 3-product bf16 split (within the stated 1e-4 tolerance)")
+    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 2, 3, 6],
+                    help="conv contraction: 2 = scaled fp16 pieces, 3 products (default, f32-equivalent error), 6 = bf16 pieces, "
+                         "6 products (f32-equivalent), 0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance)")
     args = ap.parse_args()
 
     import sgg_amd  # noqa: F401
@@ -179,9 +182,10 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(dom)
-            nprod = K.conv_precision if K.conv_precision else 1
+            nprod = {0: 1, 2: 3, 3: 3, 6: 6}[K.conv_precision]
             peak = MFMA_BF16_PEAK_TFLOPS / nprod if K.conv_precision else MFMA_F32_PEAK_TFLOPS
-            note = ("dense bf16 MFMA peak %.0f TFLOP/s / %d MFMA products per algorithmic f32 product" % (MFMA_BF16_PEAK_TFLOPS, nprod)
+            note = ("dense %s MFMA peak %.0f TFLOP/s / %d MFMA products per algorithmic f32 product"
+                    % ("f16" if K.conv_precision == 2 else "bf16", MFMA_BF16_PEAK_TFLOPS, nprod)
                     if K.conv_precision else "f32 matrix peak")
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": peak, "peak_note": note,
                                "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic,

@@ -31,33 +31,40 @@ int sgg_device_info(int* cu_count, size_t* lds_bytes_per_cu, size_t* hbm_bytes, 
  * pad_t / pad_l are the TF SAME "before" pads (pad_total // 2); the "after" pad is implied by Ho/Wo. */
 int sgg_hwio_to_hwoi(const float* w_hwio, float* w_hwoi, int taps, int cin, int cout, void* stream);
 /* forward: `w` = HWIO kernel when Cin == 3, else its HWOI transpose (sgg_hwio_to_hwoi). y = conv(x) + bias */
-/* precision: 0 = native f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32); 3 / 6 = f32 operands split into 2 / 3 bf16
- * pieces and contracted with 3 / 6 bf16 MFMAs accumulated in f32 (6: same error vs fp64 as native f32). */
+/* precision: 0 = native f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32);
+ *            2 = f32 operands scaled by a per-tensor power of two (from amax_* = device words holding max|tensor|, see
+ *                sgg_absmax / the amax_out of the LayerNorm kernels) and split into two fp16 pieces, 3 fp16 MFMAs, f32
+ *                accumulate: 22 significant bits per operand, error vs fp64 equal to native f32;
+ *            3 / 6 = split into 2 / 3 bf16 pieces, 3 / 6 bf16 MFMAs (6: f32-equivalent, 3: 2^-17 cross terms dropped).
+ * amax pointers are only read for precision 2 (may be NULL otherwise). */
 /* w_split (optional, may be NULL): the same weights pre-split by sgg_split_bf16 into precision/2 bf16 planes [P][n];
  * saves the per-workgroup split of the weight operand in the split-bf16 modes. */
-int sgg_split_bf16(const float* in, void* out, long long n, int precision, void* stream);
+int sgg_conv_split_weights(const float* in, void* out, long long n, int precision, const float* amax, void* stream);
+int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; zero it first */, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
-                        void* stream);
+                        const float* amax_x, const float* amax_w, void* stream);
 /* Conv2DBackpropInput: dx from dy and the HWIO kernel */
 int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
-                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, void* stream);
+                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                          const float* amax_dy, const float* amax_w, void* stream);
 /* Conv2DBackpropFilter: dw (HWIO) from x and dy */
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int Hi, int Wi, int Cin, int Ho,
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          const float* amax_x, const float* amax_dy, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- tf.contrib.layers.layer_norm(activation_fn=tf.nn.elu) over (H,W,C) per sample ------------------------
  * generator_with_attention.py:30..66 / discriminator_with_attention.py:30..66.  C: power of two in [4,1024].
  * fwd writes a = ELU(LN(y)) and stats[b] = (mean, rstd).  bwd writes dy, dgamma, dbeta and (optional, may be
  * NULL) dbias_prev = sum_{b,h,w} dy = the BiasAddGrad of the convolution that produced y. */
 size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C);
-int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats, int B,
-                              int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+/* amax_out (optional): device word atomically max-ed with max|output| (the consumer convolution's f16 scaling) */
+int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
+                              float* amax_out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
 int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
-                              const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev, int B,
-                              int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+                              const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
+                              float* amax_out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- initial LSTM state: tf.reduce_mean(downsampled, axis=(1,2)) -------------------------------------------
  * generator_with_attention.py:76-77.  Rows r in [0,R) use image r % B (R/B passes share one feature map). */

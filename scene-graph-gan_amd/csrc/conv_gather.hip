@@ -30,7 +30,9 @@ struct GatherParams {
   const float* wm;
   const float* bias;  // may be null
   float* out;
-  const void* w_split;  // optional: the weights pre-split into P bf16 planes [P][taps*N*C] (sgg_split_bf16), else null
+  const void* w_split;  // optional: the weights pre-split into P 16-bit planes [P][taps*N*C] (sgg_conv_split_weights), else null
+  const float* amax_src;  // f16x3 mode: device words holding max|src| and max|w| (power-of-two scaling into fp16 range)
+  const float* amax_w;
   int B, Hs, Ws, C;  // source grid, channels (= contraction length per tap), C % 32 == 0
   int N;             // output channels, N % 32 == 0
   int Ho, Wo;        // full output grid
@@ -323,27 +325,50 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
 }
-// 8 consecutive floats -> P planes of 8 bf16 (16 B each)
-template <int P>
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4 (&pl)[P]) {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+// 8 consecutive floats -> P planes of 8 sixteen-bit pieces (16 B each), x*scale = x0 + x1 (+ x2).
+//   HALF = false: bf16 pieces (RNE), scale unused.   HALF = true: fp16 pieces (P = 2) of the pre-scaled value; the scale
+//   is a power of two chosen from the tensor's max|x| so that |x*scale| <= 2^14 (no overflow, and the second piece
+//   only reaches fp16 subnormals 38 binades below the tensor's maximum): 22 significant bits in two pieces.
+template <int P, bool HALF>
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float scale, u32x4 (&pl)[P]) {
   float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float a = x[2 * q], b = x[2 * q + 1];
+    if constexpr (HALF) {
+      a *= scale; b *= scale;
+      const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+      pl[0][q] = __builtin_bit_cast(unsigned, h);
+      const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+      pl[1][q] = __builtin_bit_cast(unsigned, l);
+    } else {
 #pragma unroll
-    for (int pp = 0; pp < P; ++pp) {
-      const unsigned pk = cvt_pk_bf16(a, b);
-      pl[pp][q] = pk;
-      if (pp + 1 < P) {
-        a -= __builtin_bit_cast(float, pk << 16);
-        b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+      for (int pp = 0; pp < P; ++pp) {
+        const unsigned pk = cvt_pk_bf16(a, b);
+        pl[pp][q] = pk;
+        if (pp + 1 < P) {
+          a -= __builtin_bit_cast(float, pk << 16);
+          b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+        }
       }
     }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int P, bool WS>
+template <bool HALF>
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 c) {
+  if constexpr (HALF)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int BM, int BN, int WGM, int WGN, int P, bool WS, bool HALF>
 __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
+  static_assert(!HALF || P == 2, "f16 mode uses two pieces");
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NPA = BM / 64, NPB = (BN + 63) / 64;    // row passes: 64 rows x 4 chunks of 8 k per pass
@@ -373,6 +398,12 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
       WS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_split), 0, (p.w_bytes / 2) * P, 0x00020000)
          : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wm), 0, p.w_bytes, 0x00020000);
   const unsigned w_plane_bytes = p.w_bytes / 2;
+  int ea = 0, eb = 0;
+  if constexpr (HALF) {
+    ea = scale_exp_from_amax(*p.amax_src);
+    eb = scale_exp_from_amax(*p.amax_w);
+  }
+  const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
 
   int a_ys[NPA], a_xs[NPA], a_off[NPA];
 #pragma unroll
@@ -457,7 +488,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
       u32x4 pl[P];
-      split8<P>(ra[j][0], ra[j][1], pl);
+      split8<P, HALF>(ra[j][0], ra[j][1], sa, pl);
 #pragma unroll
       for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(A_s + pp * BM * ROWB + sw(prow + 64 * j, chunk)) = pl[pp];
     }
@@ -468,7 +499,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) pl[pp] = __builtin_bit_cast(u32x4, rb[j][pp]);
       } else {
-        split8<P>(rb[j][0], rb[j][1], pl);
+        split8<P, HALF>(rb[j][0], rb[j][1], sb, pl);
       }
       if (prow + 64 * j < BN) {
 #pragma unroll
@@ -482,30 +513,30 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[TM][P], b[TN][P];
+      u32x4 a[TM][P], b[TN][P];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
-          a[tm][pp] = *reinterpret_cast<const bf16x8*>(A_s + pp * BM * ROWB + sw(wm0 + tm * 32 + i, 2 * ks + h));
+          a[tm][pp] = *reinterpret_cast<const u32x4*>(A_s + pp * BM * ROWB + sw(wm0 + tm * 32 + i, 2 * ks + h));
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
-          b[tn][pp] = *reinterpret_cast<const bf16x8*>(B_s + pp * BN * ROWB + sw(wn0 + tn * 32 + i, 2 * ks + h));
+          b[tn][pp] = *reinterpret_cast<const u32x4*>(B_s + pp * BN * ROWB + sw(wn0 + tn * 32 + i, 2 * ks + h));
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           f32x16 d = acc[tm][tn];
           if constexpr (P == 3) {      // smallest terms first
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], d, 0, 0, 0);
+            d = mfma16<HALF>(a[tm][2], b[tn][0], d);
+            d = mfma16<HALF>(a[tm][0], b[tn][2], d);
+            d = mfma16<HALF>(a[tm][1], b[tn][1], d);
           }
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], d, 0, 0, 0);
+          d = mfma16<HALF>(a[tm][1], b[tn][0], d);
+          d = mfma16<HALF>(a[tm][0], b[tn][1], d);
+          d = mfma16<HALF>(a[tm][0], b[tn][0], d);
           acc[tm][tn] = d;
         }
     }
@@ -521,7 +552,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + tm * 32 + acc_row(r, lane);
         const int off = out_off_s[row];
-        if (off >= 0) p.out[(size_t)off + n] = acc[tm][tn][r] + bv;
+        if (off >= 0) p.out[(size_t)off + n] = HALF ? ldexpf(ldexpf(acc[tm][tn][r], -ea), -eb) + bv : acc[tm][tn][r] + bv;
       }
     }
   }
@@ -618,7 +649,7 @@ static void launch_gather3(const GatherParams& p, hipStream_t st) {
   hipLaunchKernelGGL((conv_gather3_kernel<BM, BN, WGM, WGN, BK>), grid, dim3(256), 0, st, q, src_bytes);
 }
 
-template <int BM, int BN, int WGM, int WGN, int P>
+template <int BM, int BN, int WGM, int WGN, int P, bool HALF>
 static void launch_gather_bf16s(const GatherParams& p, hipStream_t st) {
   int maxwg = 0;
   GatherParams q = p;
@@ -630,25 +661,25 @@ static void launch_gather_bf16s(const GatherParams& p, hipStream_t st) {
   const unsigned src_bytes = (unsigned)((size_t)q.B * q.Hs * q.Ws * q.C * sizeof(float));
   dim3 grid(maxwg, q.ncls, 1);
   if (q.w_split && (size_t)(q.w_bytes / 2) * P < 0x80000000ull)
-    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, true>), grid, dim3(256), 0, st, q, src_bytes);
+    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, true, HALF>), grid, dim3(256), 0, st, q, src_bytes);
   else
-    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, false>), grid, dim3(256), 0, st, q, src_bytes);
+    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, false, HALF>), grid, dim3(256), 0, st, q, src_bytes);
 }
 
-// precision: 0 = native f32 MFMA; 3 / 6 = split-bf16 with 3 / 6 products (see conv_gather_bf16s_kernel)
+// precision: 0 = native f32 MFMA; 2 = scaled f16 pieces, 3 products; 3 / 6 = bf16 pieces, 3 / 6 products
 static int dispatch_gather(const GatherParams& p, hipStream_t st, int precision) {
   const bool small_ = (size_t)p.B * p.Hs * p.Ws * p.C * sizeof(float) < 0x80000000ull && p.w_bytes < 0x80000000u;
   if (precision != 0 && small_) {
-    if (p.N % 128 == 0) {
-      if (precision == 3) launch_gather_bf16s<128, 128, 2, 2, 2>(p, st);
-      else launch_gather_bf16s<128, 128, 2, 2, 3>(p, st);
-    } else if (p.N % 64 == 0) {
-      if (precision == 3) launch_gather_bf16s<256, 64, 4, 1, 2>(p, st);
-      else launch_gather_bf16s<256, 64, 4, 1, 3>(p, st);
-    } else {
-      if (precision == 3) launch_gather_bf16s<256, 32, 4, 1, 2>(p, st);
-      else launch_gather_bf16s<256, 32, 4, 1, 3>(p, st);
-    }
+#define SGG_GB(BM, BN, WGM, WGN)                                                        \
+  do {                                                                                  \
+    if (precision == 2) launch_gather_bf16s<BM, BN, WGM, WGN, 2, true>(p, st);          \
+    else if (precision == 3) launch_gather_bf16s<BM, BN, WGM, WGN, 2, false>(p, st);    \
+    else launch_gather_bf16s<BM, BN, WGM, WGN, 3, false>(p, st);                        \
+  } while (0)
+    if (p.N % 128 == 0) SGG_GB(128, 128, 2, 2);
+    else if (p.N % 64 == 0) SGG_GB(256, 64, 4, 1);
+    else SGG_GB(256, 32, 4, 1);
+#undef SGG_GB
     return SGG_OK;
   }
   // buffer-load path: byte offsets must stay below the out-of-range marker 2^31
@@ -666,26 +697,31 @@ static int dispatch_gather(const GatherParams& p, hipStream_t st, int precision)
   return SGG_OK;
 }
 
-// f32 [n] -> P planes of bf16 [P][n] with x = x0 + x1 (+ x2), the operand format of conv_gather_bf16s_kernel<.., WS = true>
-template <int P>
-__global__ void split_bf16_kernel(const float* __restrict__ in, unsigned* __restrict__ out, long long n8) {
+// f32 [n] -> P planes of 16-bit pieces [P][n]: the operand format of conv_gather_bf16s_kernel<.., WS = true>
+template <int P, bool HALF>
+__global__ void split_weights_kernel(const float* __restrict__ in, unsigned* __restrict__ out, long long n8,
+                                     const float* __restrict__ amax) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
+  const float scale = HALF ? ldexpf(1.f, scale_exp_from_amax(*amax)) : 1.f;
   const f32x4 v0 = reinterpret_cast<const f32x4*>(in)[2 * i], v1 = reinterpret_cast<const f32x4*>(in)[2 * i + 1];
   u32x4 pl[P];
-  split8<P>(v0, v1, pl);
+  split8<P, HALF>(v0, v1, scale, pl);
 #pragma unroll
   for (int pp = 0; pp < P; ++pp) reinterpret_cast<u32x4*>(out)[(long long)pp * n8 + i] = pl[pp];
 }
 
-extern "C" int sgg_split_bf16(const float* in, void* out, long long n, int precision, void* stream) {
-  SGG_CHECK_ARG(in && out && n > 0 && n % 8 == 0 && (precision == 3 || precision == 6), "sgg_split_bf16: bad argument");
+// `amax` (device word with max|w|, see sgg_absmax) is required for precision 2 and ignored otherwise
+extern "C" int sgg_conv_split_weights(const float* in, void* out, long long n, int precision, const float* amax, void* stream) {
+  SGG_CHECK_ARG(in && out && n > 0 && n % 8 == 0 && (precision == 2 || precision == 3 || precision == 6) && (precision != 2 || amax),
+                "sgg_conv_split_weights: bad argument");
   const long long n8 = n / 8;
-  if (precision == 3)
-    hipLaunchKernelGGL(split_bf16_kernel<2>, dim3(sgg_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, in, (unsigned*)out, n8);
-  else
-    hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(sgg_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, in, (unsigned*)out, n8);
-  SGG_LAUNCH_CHECK("sgg_split_bf16");
+  const dim3 grid(sgg_cdiv(n8, 256)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == 2) hipLaunchKernelGGL((split_weights_kernel<2, true>), grid, blk, 0, st, in, (unsigned*)out, n8, amax);
+  else if (precision == 3) hipLaunchKernelGGL((split_weights_kernel<2, false>), grid, blk, 0, st, in, (unsigned*)out, n8, amax);
+  else hipLaunchKernelGGL((split_weights_kernel<3, false>), grid, blk, 0, st, in, (unsigned*)out, n8, amax);
+  SGG_LAUNCH_CHECK("sgg_conv_split_weights");
   return SGG_OK;
 }
 
@@ -700,9 +736,10 @@ extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, in
 // Forward. `w` is the HWIO kernel for Cin == 3 and the HWOI transpose (sgg_hwio_to_hwoi) otherwise.
 extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi,
                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
-                                   int precision, void* stream) {
+                                   int precision, const float* amax_x, const float* amax_w, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
-  SGG_CHECK_ARG(precision == 0 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 3 or 6");
+  SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 2, 3 or 6");
+  SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 2 needs the amax words");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_fwd: bad dims");
   SGG_CHECK_ARG(Ho == (Hi + stride - 1) / stride && Wo == (Wi + stride - 1) / stride,
                 "sgg_conv2d_nhwc_fwd: Ho/Wo must be ceil(in/stride) (SAME padding)");
@@ -720,6 +757,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_fwd: Cin and Cout must be multiples of 32 (or Cin == 3)");
   GatherParams p;
   p.src = x; p.wm = w; p.bias = bias; p.out = y; p.w_split = (precision != 0) ? w_split : nullptr;
+  p.amax_src = amax_x; p.amax_w = amax_w;
   p.B = B; p.Hs = Hi; p.Ws = Wi; p.C = Cin; p.N = Cout; p.Ho = Ho; p.Wo = Wo;
   p.sy = stride; p.sx = stride; p.dy = 1; p.dx = 1; p.osy = 1; p.osx = 1; p.KW = KW;
   p.ncls = 1;
@@ -735,15 +773,17 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
 // dgrad: dx[B,Hi,Wi,Cin] = conv-transpose of dy[B,Ho,Wo,Cout] with the HWIO kernel w (no bias).
 extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
-                                     void* stream) {
+                                     const float* amax_dy, const float* amax_w, void* stream) {
   SGG_CHECK_ARG(dy && w && dx, "sgg_conv2d_nhwc_dgrad: null pointer");
-  SGG_CHECK_ARG(precision == 0 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_dgrad: precision must be 0, 3 or 6");
+  SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_dgrad: precision must be 0, 2, 3 or 6");
+  SGG_CHECK_ARG(precision != 2 || (amax_dy && amax_w), "sgg_conv2d_nhwc_dgrad: precision 2 needs the amax words");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_dgrad: bad dims");
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_dgrad: Cin and Cout must be multiples of 32");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
                 "sgg_conv2d_nhwc_dgrad: tensor exceeds 2^31 elements");
   GatherParams p;
   p.src = dy; p.wm = w; p.bias = nullptr; p.out = dx; p.w_split = (precision != 0) ? w_split : nullptr;
+  p.amax_src = amax_dy; p.amax_w = amax_w;
   p.B = B; p.Hs = Ho; p.Ws = Wo; p.C = Cout; p.N = Cin; p.Ho = Hi; p.Wo = Wi;
   p.sy = 1; p.sx = 1; p.dy = -1; p.dx = -1; p.osy = stride; p.osx = stride; p.KW = KW;
   p.ncls = stride * stride;

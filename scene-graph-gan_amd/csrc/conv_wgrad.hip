@@ -14,50 +14,66 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// 8 floats -> P bf16 pieces (x = x0 + x1 (+ x2)), each packed as 8 bf16 (see conv_gather_bf16s_kernel)
-template <int P>
-__device__ __forceinline__ void split8_regs(const float (&x)[8], bf16x8 (&out)[P]) {
-  u32x4 pl[P];
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+// 8 floats -> P sixteen-bit pieces: bf16 (x = x0 + x1 (+ x2)) or, HALF, fp16 pieces of x*scale (see conv_gather_bf16s_kernel)
+template <int P, bool HALF>
+__device__ __forceinline__ void split8_regs(const float (&x)[8], float scale, u32x4 (&pl)[P]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float a = x[2 * q], b = x[2 * q + 1];
+    if constexpr (HALF) {
+      a *= scale; b *= scale;
+      const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+      pl[0][q] = __builtin_bit_cast(unsigned, h);
+      const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+      pl[1][q] = __builtin_bit_cast(unsigned, l);
+    } else {
 #pragma unroll
-    for (int pp = 0; pp < P; ++pp) {
-      const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));
-      pl[pp][q] = pk;
-      if (pp + 1 < P) {
-        a -= __builtin_bit_cast(float, pk << 16);
-        b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+      for (int pp = 0; pp < P; ++pp) {
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));
+        pl[pp][q] = pk;
+        if (pp + 1 < P) {
+          a -= __builtin_bit_cast(float, pk << 16);
+          b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+        }
       }
     }
   }
-#pragma unroll
-  for (int pp = 0; pp < P; ++pp) out[pp] = __builtin_bit_cast(bf16x8, pl[pp]);
+}
+
+template <bool HALF>
+__device__ __forceinline__ f32x16 mfma16w(const u32x4& a, const u32x4& b, f32x16 c) {
+  if constexpr (HALF)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // Split-bf16 contraction of MC tiles (f32 in LDS, [pixel][channel]): each wave gathers its fragments with the pixel
 // (= k) index running down the LDS rows (ds_read_b32, conflict free), splits them in registers and issues
 // 3 (P = 2) or 6 (P = 3) v_mfma_f32_32x32x16_bf16 per tile and 16-pixel step.  k_count must be a multiple of 16.
-template <int TM, int TN, int P>
+template <int TM, int TN, int P, bool HALF>
 __device__ __forceinline__ void mma_slab_mc_mc_split(const float* __restrict__ A_s, int lda_s, const float* __restrict__ B_s,
                                                      int ldb_s, int wm0, int wn0, int k_begin, int k_count, int lane,
-                                                     f32x16 (&acc)[TM][TN]) {
+                                                     float sa, float sb, f32x16 (&acc)[TM][TN]) {
   const int i = lane & 31, h = lane >> 5;
   for (int k = k_begin; k < k_begin + k_count; k += 16) {
-    bf16x8 a[TM][P], b[TN][P];
+    u32x4 a[TM][P], b[TN][P];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = A_s[(k + 8 * h + j) * lda_s + wm0 + tm * 32 + i];
-      split8_regs<P>(x, a[tm]);
+      split8_regs<P, HALF>(x, sa, a[tm]);
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = B_s[(k + 8 * h + j) * ldb_s + wn0 + tn * 32 + i];
-      split8_regs<P>(x, b[tn]);
+      split8_regs<P, HALF>(x, sb, b[tn]);
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -65,13 +81,13 @@ __device__ __forceinline__ void mma_slab_mc_mc_split(const float* __restrict__ A
       for (int tn = 0; tn < TN; ++tn) {
         f32x16 d = acc[tm][tn];
         if constexpr (P == 3) {
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], d, 0, 0, 0);
+          d = mfma16w<HALF>(a[tm][2], b[tn][0], d);
+          d = mfma16w<HALF>(a[tm][0], b[tn][2], d);
+          d = mfma16w<HALF>(a[tm][1], b[tn][1], d);
         }
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], d, 0, 0, 0);
+        d = mfma16w<HALF>(a[tm][1], b[tn][0], d);
+        d = mfma16w<HALF>(a[tm][0], b[tn][1], d);
+        d = mfma16w<HALF>(a[tm][0], b[tn][0], d);
         acc[tm][tn] = d;
       }
   }
@@ -85,9 +101,11 @@ struct WgradParams {
   int Mpix, chunk, ntile_n;
   unsigned magic_wo, magic_ho;   // ceil(2^32 / Wo), ceil(2^32 / Ho): exact division by __umulhi for our ranges
   unsigned x_bytes, dy_bytes;    // buffer descriptor bounds
+  const float* amax_x;           // f16x3 mode: device words with max|x|, max|dy|
+  const float* amax_dy;
 };
 
-template <int BMC, int BNC, int WM, int WN, int P>
+template <int BMC, int BNC, int WM, int WN, int P, bool HALF>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p) {
   constexpr int WGM = BMC / WM, WGN = BNC / WN, WGK = 4 / (WGM * WGN);
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -118,6 +136,12 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p) {
 
   f32x16 acc[TM][TN];
   acc_zero<TM, TN>(acc);
+  int ea = 0, eb = 0;
+  if constexpr (HALF) {
+    ea = scale_exp_from_amax(*p.amax_x);
+    eb = scale_exp_from_amax(*p.amax_dy);
+  }
+  const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
 
   constexpr int A_CPR = BMC / 4, B_CPR = BNC / 4;  // float4 per row
   // Branch-free slab fetch (same recipe as conv_gather3_kernel): raw buffer loads, rows past the pixel range or
@@ -168,10 +192,18 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p) {
       mma_slab_mc_mc<TM, TN>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
     } else {
       static_assert(P == 0 || KROWS % 16 == 0, "bf16 MFMA step is 16 pixels deep");
-      mma_slab_mc_mc_split<TM, TN, P>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, acc);
+      mma_slab_mc_mc_split<TM, TN, P, HALF>(A_s, BMC, B_s, BNC, wm0, wn0, wk * KROWS, KROWS, lane, sa, sb, acc);
     }
   }
 
+  if constexpr (HALF) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = ldexpf(ldexpf(acc[tm][tn][r], -ea), -eb);
+  }
   if constexpr (WGK > 1) {
     // reduce the k-split waves through LDS: red[wave][slot][lane]
     __syncthreads();
@@ -316,9 +348,12 @@ extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, i
 
 extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     const float* amax_x, const float* amax_dy, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
   SGG_CHECK_ARG(x && dy && dw, "sgg_conv2d_nhwc_wgrad: null pointer");
-  SGG_CHECK_ARG(precision == 0 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_wgrad: precision must be 0, 3 or 6");
+  SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6,
+                "sgg_conv2d_nhwc_wgrad: precision must be 0, 2, 3 or 6");
+  SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_dy), "sgg_conv2d_nhwc_wgrad: precision 2 needs the amax words");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_wgrad: bad dims");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
                 "sgg_conv2d_nhwc_wgrad: tensor exceeds 2^31 elements");
@@ -351,6 +386,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   p.Mpix = B * Ho * Wo; p.chunk = pl.chunk; p.ntile_n = Cout / pl.bnc;
   p.magic_wo = (unsigned)((0x100000000ull + Wo - 1) / Wo);
   p.magic_ho = (unsigned)((0x100000000ull + Ho - 1) / Ho);
+  p.amax_x = amax_x; p.amax_dy = amax_dy;
   p.x_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
   p.dy_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
   // multiply-high division is exact while n * d < 2^32 (n = pixel index + 31, d = Wo; then n / Wo and Ho)
@@ -361,9 +397,10 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   dim3 grid(pl.tiles, KH * KW, pl.nsplit);
 #define SGG_WG(BMC, BNC, WM, WN)                                                                        \
   do {                                                                                                \
-    if (precision == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 0>), grid, dim3(256), 0, st, p);      \
-    else if (precision == 3) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 2>), grid, dim3(256), 0, st, p); \
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 3>), grid, dim3(256), 0, st, p);                     \
+    if (precision == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 0, false>), grid, dim3(256), 0, st, p);      \
+    else if (precision == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 2, true>), grid, dim3(256), 0, st, p);  \
+    else if (precision == 3) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 2, false>), grid, dim3(256), 0, st, p); \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 3, false>), grid, dim3(256), 0, st, p);                     \
   } while (0)
   if (pl.bmc == 32 && pl.bnc == 32) SGG_WG(32, 32, 32, 32);
   else if (pl.bmc == 32 && pl.bnc == 64) SGG_WG(32, 64, 32, 32);

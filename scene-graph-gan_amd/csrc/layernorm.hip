@@ -102,10 +102,11 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x);
 __global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ part,
                                                            float* __restrict__ a, float* __restrict__ stats, long long N,
-                                                           int C, int G, int cpg) {
+                                                           int C, int G, int cpg, float* __restrict__ amax_out) {
   __shared__ float red[4];
   const int b = blockIdx.y, g = blockIdx.x;
   float mean, rstd;
+  float amax = 0.f;
   ln_merge(part + (size_t)b * G * 3, G, (float)N, red, mean, rstd);
   if (g == 0 && threadIdx.x == 0) {
     stats[b * 2 + 0] = mean;
@@ -128,9 +129,14 @@ __global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restri
         const f32x4 v = *reinterpret_cast<const f32x4*>(yb + e);
         f32x4 o = v * inv + shift;
         o[0] = elu1(o[0]); o[1] = elu1(o[1]); o[2] = elu1(o[2]); o[3] = elu1(o[3]);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         *reinterpret_cast<f32x4*>(ab + e) = o;
       }
     }
+  }
+  if (amax_out) {   // max |a| of the tensor (for the consumer convolution's f16 scaling)
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) atomic_amax(amax_out, amax);
   }
 }
 
@@ -255,10 +261,12 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
 __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ da,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ stats, const float* __restrict__ sspart,
-                                                           float* __restrict__ dy, long long N, int C, int G, int cpg) {
+                                                           float* __restrict__ dy, long long N, int C, int G, int cpg,
+                                                           float* __restrict__ amax_out) {
   __shared__ float red[4];
   const int b = blockIdx.y, g = blockIdx.x;
   const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
+  float amax = 0.f;
   float a1 = 0.f, a2 = 0.f;
   for (int i = threadIdx.x; i < G; i += 256) {
     a1 += sspart[((size_t)b * G + i) * 2 + 0];
@@ -288,10 +296,15 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
         for (int q = 0; q < 4; ++q) {
           const float dn = d[q] * (n[q] > 0.f ? 1.f : __expf(n[q]));
           o[q] = rstd * (dn * gm[q] - m1 - xh[q] * m2);
+          amax = fmaxf(amax, fabsf(o[q]));
         }
         *reinterpret_cast<f32x4*>(ob + e) = o;
       }
     }
+  }
+  if (amax_out) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) atomic_amax(amax_out, amax);
   }
 }
 
@@ -312,8 +325,8 @@ static int ln_check(const char* name, int B, int HW, int C, size_t ws_bytes, voi
   return SGG_OK;
 }
 
-extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats, int B,
-                                         int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
+                                         float* amax_out, int B, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
   SGG_CHECK_ARG(y && gamma && beta && a && stats, "sgg_layernorm_hwc_elu_fwd: null pointer");
   int rc = ln_check("sgg_layernorm_hwc_elu_fwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
@@ -322,14 +335,14 @@ extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, con
   float* part = (float*)ws;
   hipLaunchKernelGGL(ln_stats_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg);
   hipLaunchKernelGGL(ln_apply_elu_kernel, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)part, a, stats, g.N,
-                     C, g.G, g.cpg);
+                     C, g.G, g.cpg, amax_out);
   SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_fwd");
   return SGG_OK;
 }
 
 extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
-                                         const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev, int B,
-                                         int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+                                         const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
+                                         float* amax_out, int B, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
   SGG_CHECK_ARG(y && da && gamma && beta && stats && dy && dgamma && dbeta, "sgg_layernorm_hwc_elu_bwd: null pointer");
   int rc = ln_check("sgg_layernorm_hwc_elu_bwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
@@ -343,7 +356,7 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sspart,
                      (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, HW);
   hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, (const float*)sspart, dy,
-                     g.N, C, g.G, g.cpg);
+                     g.N, C, g.G, g.cpg, amax_out);
   SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd");
   return SGG_OK;
 }

@@ -151,12 +151,36 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if (lane == 0) out[row] = (long long)bi;
 }
 
+// amax[0] = max(amax[0], max |x|)   (caller zeroes amax first); used to scale tensors for the f16x3 conv mode
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ amax) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_amax(amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------
 static inline int grid_for(long long n, int block) {
   long long g = (n + block - 1) / block;
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;
   return (int)g;
+}
+
+extern "C" int sgg_absmax(const float* x, long long n, float* amax, void* stream) {
+  SGG_CHECK_ARG(x && amax && n > 0 && (((uintptr_t)x) & 15) == 0, "sgg_absmax: bad argument");
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256) > 1024 ? 1024 : grid_for(n / 4 + 1, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, n, amax);
+  SGG_LAUNCH_CHECK("sgg_absmax");
+  return SGG_OK;
 }
 
 extern "C" int sgg_fill(float* p, long long n, float value, void* stream) {

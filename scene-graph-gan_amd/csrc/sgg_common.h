@@ -56,6 +56,20 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- per-tensor power-of-two scaling for the f16x3 convolution mode --------------------------------------
+// amax words hold max|x| of a tensor as float bits (non-negative floats order like unsigned ints -> atomicMax).
+__device__ __forceinline__ void atomic_amax(float* p, float v) {
+  atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
+}
+// exponent e with |x| * 2^e <= 2^14 for every |x| <= amax (fp16 max is 65504); 0 for an all-zero tensor
+__device__ __forceinline__ int scale_exp_from_amax(float amax) {
+  if (!(amax > 0.f)) return 0;
+  int k;
+  frexpf(amax, &k);           // amax = m * 2^k, m in [0.5, 1)
+  const int e = 14 - k;
+  return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+
 // XCD-aware bijective block remap (cdna_hip_programming.md T1): consecutive logical ids share an XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;

@@ -28,14 +28,15 @@ SIGNATURES = {
     "sgg_last_error": (c_char_p, []),
     "sgg_device_info": (_i, [_vp, _vp, _vp, _vp, _i]),
     "sgg_hwio_to_hwoi": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "sgg_split_bf16": (_i, [_vp, _vp, _ll, _i, _vp]),
-    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
-    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "sgg_conv_split_weights": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
+    "sgg_absmax": (_i, [_vp, _ll, _vp, _vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp]),
+    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
-    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _sz, _vp]),
+    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_vp, _sz, _vp]),
-    "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 9 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 6 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 3 + [_vp, _sz, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -114,12 +115,14 @@ class HipKernels:
         self._ws_by_stream = {}
         self.timing = None      # bench.py sets this to a list: conv launches are then bracketed by HIP events
         # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
-        #   6 (default) f32 operands split into three bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate: the error
-        #               against fp64 equals the native f32 path's (dropped terms are 2^-27 relative), 1.35-1.5x faster;
+        #   2 (default) f32 operands scaled by a per-tensor power of two and split into two fp16 pieces (22 significant
+        #               bits), 3 fp16 MFMAs per product, f32 accumulate: error against fp64 equal to the native f32 path's;
+        #   6           three bf16 pieces, 6 bf16 MFMAs (no scaling needed): also f32-equivalent, slower;
         #   0           native f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 fmaf chain);
-        #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance), fastest.
-        self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "6"))
-        assert self.conv_precision in (0, 3, 6)
+        #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance).
+        self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
+        assert self.conv_precision in (0, 2, 3, 6)
+        self._amax_scratch = torch.zeros(8, dtype=torch.float32, device=self.device)
 
     def _timed(self, symbol, flops, fn):
         """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline leg)."""
@@ -136,7 +139,7 @@ class HipKernels:
         """Kernel symbol the implicit-GEMM dispatcher (csrc/conv_gather.hip: dispatch_gather) picks for N outputs."""
         if self.conv_precision:
             tile = "128,128,2,2" if n_out % 128 == 0 else ("256,64,4,1" if n_out % 64 == 0 else "256,32,4,1")
-            return "conv_gather_bf16s_kernel<%s,%d>" % (tile, 2 if self.conv_precision == 3 else 3)
+            return "conv_gather_bf16s_kernel<%s,%s>" % (tile, {2: "2,f16", 3: "2,bf16", 6: "3,bf16"}[self.conv_precision])
         if n_out % 128 == 0:
             return "conv_gather3_kernel<128,128,2,2,32>"
         return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather3_kernel<256,32,4,1,32>"
@@ -185,54 +188,79 @@ class HipKernels:
         Wo, pl, _ = same_pads(Wi, KW, stride)
         return B, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, stride, pt, pl
 
-    def split_bf16(self, w, out):
-        """w fp32 (n % 8 == 0) -> out int16 [P, n] bf16 planes for the current conv precision (3 -> P=2, 6 -> P=3)."""
-        self._dev(w, out)
-        self._check(self.lib.sgg_split_bf16(_p(w), _p(out), w.numel(), self.conv_precision, self._stream()), "sgg_split_bf16")
+    def absmax(self, x, amax):
+        """amax (1-element fp32 view, zeroed by the caller) = max(amax, max|x|)."""
+        self._dev(x, amax)
+        assert x.is_contiguous()
+        self._check(self.lib.sgg_absmax(_p(x), x.numel(), _p(amax), self._stream()), "sgg_absmax")
 
-    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None):
+    def _amax_or_compute(self, t, amax, slot):
+        """precision 2 needs max|t| on the device; callers that track it pass `amax`, otherwise it is computed here."""
+        if self.conv_precision != 2 or amax is not None or t is None:
+            return amax
+        w = self._amax_scratch[slot:slot + 1]
+        self.fill(w, 0.0)
+        self.absmax(t, w)
+        return w
+
+    def split_weights(self, w, out, amax=None):
+        """w fp32 (n % 8 == 0) -> out int16 [P, n] sixteen-bit planes for the current conv precision."""
+        self._dev(w, out, amax)
+        amax = self._amax_or_compute(w, amax, 2)
+        self._check(self.lib.sgg_conv_split_weights(_p(w), _p(out), w.numel(), self.conv_precision, _p(amax), self._stream()),
+                    "sgg_conv_split_weights")
+
+    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
         self._dev(x, w_fwd, bias, y)
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else self.gather_symbol(d[6])
+        if d[3] != 3:
+            amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
-            _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_fwd")
+            _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, _p(amax_x), _p(amax_w), self._stream())),
+            "sgg_conv2d_nhwc_fwd")
 
-    def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None):
+    def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None):
         self._dev(dy, w_hwio, dx)
         d = self._conv_dims(dx.shape, w_hwio.shape, stride)
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
+        amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
         self._check(self._timed(self.gather_symbol(d[3]), flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
-            _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, self._stream())), "sgg_conv2d_nhwc_dgrad")
+            _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, _p(amax_dy), _p(amax_w), self._stream())),
+            "sgg_conv2d_nhwc_dgrad")
 
-    def conv_wgrad(self, x, dy, dw, stride):
+    def conv_wgrad(self, x, dy, dw, stride, amax_x=None, amax_dy=None):
         self._dev(x, dy, dw)
         d = self._conv_dims(x.shape, dw.shape, stride)
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous()
         need = self.lib.sgg_conv2d_nhwc_wgrad_workspace_bytes(*d[:9])
         ws = self.workspace(need)
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
+        if d[3] != 3:
+            amax_x, amax_dy = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(dy, amax_dy, 1)
         self._check(self._timed("conv_wgrad(call: wgrad kernel + slab reduce)", flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
-            _p(x), _p(dy), _p(dw), *d, self.conv_precision, _p(ws), ws.numel(), self._stream())), "sgg_conv2d_nhwc_wgrad")
+            _p(x), _p(dy), _p(dw), *d, self.conv_precision, _p(amax_x), _p(amax_dy), _p(ws), ws.numel(), self._stream())),
+            "sgg_conv2d_nhwc_wgrad")
 
-    def ln_elu_fwd(self, y, gamma, beta, a, stats):
-        self._dev(y, gamma, beta, a, stats)
+    def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None):
+        self._dev(y, gamma, beta, a, stats, amax_out)
         B, H, W, C = y.shape
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
         ws = self.workspace(need)
-        self._check(self.lib.sgg_layernorm_hwc_elu_fwd(_p(y), _p(gamma), _p(beta), _p(a), _p(stats), B, H * W, C, _p(ws),
+        self._check(self.lib.sgg_layernorm_hwc_elu_fwd(_p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), B, H * W, C, _p(ws),
                                                        ws.numel(), self._stream()), "sgg_layernorm_hwc_elu_fwd")
 
-    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev):
-        self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev)
+    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None):
+        self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out)
         B, H, W, C = y.shape
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
         ws = self.workspace(need)
         self._check(self.lib.sgg_layernorm_hwc_elu_bwd(_p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma),
-                                                       _p(dbeta), _p(dbias_prev), B, H * W, C, _p(ws), ws.numel(),
+                                                       _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C, _p(ws), ws.numel(),
                                                        self._stream()), "sgg_layernorm_hwc_elu_bwd")
 
     # -- heads -----------------------------------------------------------------------------------------

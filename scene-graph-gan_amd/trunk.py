@@ -37,9 +37,9 @@ class Trunk:
                 "y": torch.empty((B, ho, wo, cout), device=dev, dtype=dt),
             }
             lay["w_fwd"] = lay["w"] if cin == 3 else torch.empty((k, k, cout, cin), device=dev, dtype=dt)
-            # split-bf16 modes: both weight layouts pre-split into bf16 planes once per optimiser step (HIP backend only)
+            # split modes: both weight layouts pre-split into 16-bit planes once per optimiser step (HIP backend only)
             lay["ws_fwd"] = lay["ws_bwd"] = None
-            if cin != 3 and getattr(K, "conv_precision", 0) and hasattr(K, "split_bf16"):
+            if cin != 3 and getattr(K, "conv_precision", 0) and hasattr(K, "split_weights"):
                 lay["ws_fwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
                 lay["ws_bwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
             if has_ln:
@@ -54,16 +54,29 @@ class Trunk:
         self.L = h * w
         self._dA = torch.empty(max_act, device=dev, dtype=dt)
         self._dY = torch.empty(max_act, device=dev, dtype=dt)
+        # f16x3 mode: device words with max|tensor| of every conv operand (rows: activations a_j, gradients dy_j,
+        # weights w_j), maintained by the producing kernels, so operands can be scaled into fp16 range without a host sync
+        self.amax = torch.zeros((3, 16), device=dev, dtype=torch.float32)
         self.refresh_weights()
+
+    def _f16(self):
+        return getattr(self.K, "conv_precision", 0) == 2
+
+    def _am(self, row, j):
+        return self.amax[row, j:j + 1] if self._f16() else None
 
     def refresh_weights(self):
         """Re-derive the HWOI forward layout after the parameters changed (Adam step / state-dict load)."""
-        for lay in self.layers:
+        if self._f16():
+            self.K.fill(self.amax[2], 0.0)
+        for j, lay in enumerate(self.layers):
             if lay["cin"] != 3:
                 self.K.hwio_to_hwoi(lay["w"], lay["w_fwd"])
+                if self._f16():
+                    self.K.absmax(lay["w"], self._am(2, j))
                 if lay["ws_fwd"] is not None and self.K.conv_precision:
-                    self.K.split_bf16(lay["w_fwd"], lay["ws_fwd"])
-                    self.K.split_bf16(lay["w"], lay["ws_bwd"])
+                    self.K.split_weights(lay["w_fwd"], lay["ws_fwd"], self._am(2, j))
+                    self.K.split_weights(lay["w"], lay["ws_bwd"], self._am(2, j))
                     lay["ws_mode"] = self.K.conv_precision
 
     def forward(self, images):
@@ -72,13 +85,19 @@ class Trunk:
         K = self.K
         self.images = images
         x = images
-        for lay in self.layers:
-            if lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision:
-                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], lay["ws_fwd"])
+        if self._f16():
+            K.fill(self.amax[0], 0.0)
+        for j, lay in enumerate(self.layers):
+            ws = lay["ws_fwd"] if (lay["ws_fwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
+            if ws is not None or self._f16():
+                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j))
             else:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             if lay["has_ln"]:
-                K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"])
+                if self._f16():
+                    K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], self._am(0, j))
+                else:
+                    K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"])
                 x = lay["a"]
             else:
                 x = lay["y"]
@@ -89,10 +108,17 @@ class Trunk:
         K, B = self.K, self.B
         dy = dctx.view(B, self.Hf, self.Wf, FEAT_C)
         n = len(self.layers)
+        f16 = self._f16()
+        if f16:
+            K.fill(self.amax[1], 0.0)
+            K.absmax(dy, self._am(1, n - 1))
         for j in range(n - 1, -1, -1):
             lay = self.layers[j]
             x_in = self.images if j == 0 else self.layers[j - 1]["a"]
-            K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
+            if f16:
+                K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
+            else:
+                K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
             if not lay["has_ln"]:
                 # last conv: BiasAddGrad = column sums of dy (LN layers get theirs from ln_elu_bwd below)
                 K.colsum(dy.view(-1, lay["cout"]), lay["gb"], False)
@@ -102,9 +128,14 @@ class Trunk:
             numel = prev["a"].numel()
             dA = self._dA[:numel].view(prev["out_shape"])
             dYp = self._dY[:numel].view(prev["out_shape"])
-            if lay["ws_bwd"] is not None and lay.get("ws_mode") == K.conv_precision:
-                K.conv_dgrad(dy, lay["w"], dA, lay["s"], lay["ws_bwd"])
+            ws = lay["ws_bwd"] if (lay["ws_bwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
+            if ws is not None or f16:
+                K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j))
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])
-            K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"])
+            if f16:
+                K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"],
+                             self._am(1, j - 1))
+            else:
+                K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"])
             dy = dYp

@@ -1,4 +1,4 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python -m pytest tests -m gpu -q 2>&1 | tail -2
+timeout -k 10 500 python -m pytest tests -m gpu -q -x 2>&1 | tail -12
 bash scripts/gpu_bench_short.sh

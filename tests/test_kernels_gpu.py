@@ -53,13 +53,14 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=[0, 6, 3], ids=["f32mfma", "bf16x6", "bf16x3"])
+@pytest.fixture(params=[0, 2, 6, 3], ids=["f32mfma", "f16x3", "bf16x6", "bf16x3"])
 def conv_mode(request, hip):
-    """conv precision modes of the C ABI: native f32 MFMA, and f32 operands split into bf16 pieces (6 / 3 products).
-    Tolerance vs the fp64 reference: f32 and bf16x6 2e-5 * max|ref|, bf16x3 (drops 2^-17 cross terms) 1e-4."""
+    """conv precision modes of the C ABI: native f32 MFMA, f32 operands scaled and split into two fp16 pieces (3 products),
+    or into bf16 pieces (6 / 3 products).  Tolerance vs the fp64 reference: f32, f16x3 and bf16x6 2e-5 * max|ref|
+    (f32-equivalent), bf16x3 (drops 2^-17 cross terms) 1e-4."""
     old = hip.conv_precision
     hip.conv_precision = request.param
-    yield {0: 2e-5, 6: 2e-5, 3: 1e-4}[request.param]
+    yield {0: 2e-5, 2: 2e-5, 6: 2e-5, 3: 1e-4}[request.param]
     hip.conv_precision = old
 
 
@@ -90,7 +91,7 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, case, conv_mode):
     close(y, y_ref, rtol=conv_mode, what="conv_fwd %s" % (case,))
     if hip.conv_precision and Ci != 3:      # same result with the weights pre-split into bf16 planes
         ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
-        hip.split_bf16(wf, ws)
+        hip.split_weights(wf, ws)
         y2 = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
         hip.conv_fwd(xd, wd, wf, bd, y2, s, ws)
         assert torch.equal(y2, y), "pre-split weights must give bit-identical outputs"
@@ -105,7 +106,7 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, case, conv_mode):
         close(dx, dx_ref, rtol=conv_mode, what="conv_dgrad %s" % (case,))
         if hip.conv_precision:
             ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
-            hip.split_bf16(wd, ws)
+            hip.split_weights(wd, ws)
             dx2 = torch.full_like(xd, float("nan"))
             hip.conv_dgrad(dyd, wd, dx2, s, ws)
             assert torch.equal(dx2, dx)
