@@ -8,7 +8,8 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), os.path.join(dst, "%s_rocprofv3_kernel_stats.csv" % tag))
 for f in ("bench.json", "bench_under_rocprof.json", "pytest_gpu.log", "bench_precision0_native_f32_mfma.json",
-          "bench_precision3_bf16x3.json"):
+          "bench_precision3_bf16x3.json", "bench_precision6_bf16x6.json", "bench_critic_iters10.json", "configs45.log",
+          "dp_rehearsal.log"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
 
