@@ -134,10 +134,7 @@ __global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restri
       }
     }
   }
-  if (amax_out) {   // max |a| of the tensor (for the consumer convolution's f16 scaling)
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0) atomic_amax(amax_out, amax);
-  }
+  if (amax_out) block_publish_amax(amax_out, amax, red);   // max |a| (the consumer convolution's f16 scaling)
 }
 
 // ---- backward ----------------------------------------------------------------------------------------
@@ -302,10 +299,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
       }
     }
   }
-  if (amax_out) {
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0) atomic_amax(amax_out, amax);
-  }
+  if (amax_out) block_publish_amax(amax_out, amax, red);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------

@@ -59,7 +59,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // ---- per-tensor power-of-two scaling for the f16x3 convolution mode --------------------------------------
 // amax words hold max|x| of a tensor as float bits (non-negative floats order like unsigned ints -> atomicMax).
 __device__ __forceinline__ void atomic_amax(float* p, float v) {
-  atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
+  // thousands of workgroups publish into one word (a single address sustains ~88 atomics/us): skip the atomic when the
+  // word already holds a larger value, which is the case for all but the first few arrivals
+  const unsigned bits = __float_as_uint(v);
+  if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(reinterpret_cast<unsigned*>(p), bits);
+}
+// block-wide (256 threads) max published once per workgroup; `red` is >= 4 floats of LDS
+__device__ __forceinline__ void block_publish_amax(float* p, float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_amax(p, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 // exponent e with |x| * 2^e <= 2^14 for every |x| <= amax (fp16 max is 65504); 0 for an all-zero tensor
 __device__ __forceinline__ int scale_exp_from_amax(float amax) {

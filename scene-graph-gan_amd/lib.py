@@ -135,11 +135,13 @@ class HipKernels:
         self.timing.append((symbol, flops, e0, e1))
         return r
 
-    def gather_symbol(self, n_out):
-        """Kernel symbol the implicit-GEMM dispatcher (csrc/conv_gather.hip: dispatch_gather) picks for N outputs."""
+    def gather_symbol(self, n_out, presplit=False):
+        """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_gather.hip: dispatch_gather picks."""
         if self.conv_precision:
             tile = "128,128,2,2" if n_out % 128 == 0 else ("256,64,4,1" if n_out % 64 == 0 else "256,32,4,1")
-            return "conv_gather_bf16s_kernel<%s,%s>" % (tile, {2: "2,f16", 3: "2,bf16", 6: "3,bf16"}[self.conv_precision])
+            return "conv_gather_bf16s_kernel<%s,%d,%s,%s>" % (tile, 3 if self.conv_precision == 6 else 2,
+                                                             "true" if presplit else "false",
+                                                             "true" if self.conv_precision == 2 else "false")
         if n_out % 128 == 0:
             return "conv_gather3_kernel<128,128,2,2,32>"
         return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather3_kernel<256,32,4,1,32>"
@@ -216,7 +218,7 @@ class HipKernels:
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else self.gather_symbol(d[6])
+        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else self.gather_symbol(d[6], w_split is not None)
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
@@ -229,7 +231,7 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        self._check(self._timed(self.gather_symbol(d[3]), flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
+        self._check(self._timed(self.gather_symbol(d[3], w_split is not None), flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, _p(amax_dy), _p(amax_w), self._stream())),
             "sgg_conv2d_nhwc_dgrad")
 
