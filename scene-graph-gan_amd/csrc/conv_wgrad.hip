@@ -241,6 +241,194 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p) {
       }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 128 x 128 channel tiles in the split modes: split ONCE at the LDS write, transpose in the LDS read.
+// The register-split kernel above converts every element in two waves (the 2x2 wave grid shares operand rows) and is
+// VALU-bound (256 conversions + 64 ds_read_b32 per lane and slab against 768 cycles of MFMA).  Here each staged
+// float4 (4 channels of one pixel) is split into P x 4 sixteen-bit pieces and written with ds_write_b64 into planes
+// [32 pixels][128 channels] (256-B rows), and the MFMA fragments - 8 consecutive PIXELS of one channel per lane -
+// are fetched with ds_read_b64_tr_b16 (gfx950 transposing LDS read: a 16-lane group reads a 4-pixel x 16-channel
+// block and each lane receives one channel's 4 pixels; semantics verified by scripts/ubench/tr16_probe.hip).
+// 16-B chunks are XOR-swizzled with f(row) = ((row&3)<<2) | ((row>>2)&3) (cdna_hip_programming.md T10, image (b)).
+// ---------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define TR_ROWB 256
+
+__device__ __forceinline__ int tr_off(int row, int chunk) {      // byte offset of 16-B chunk `chunk` of pixel row `row`
+  return row * TR_ROWB + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+__device__ __forceinline__ u32x2 ds_read_tr16(const unsigned char* p) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
+}
+
+template <int P, bool HALF>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_tr_kernel(WgradParams p) {
+  constexpr int TM = 2, TN = 2, NPA = 4, NPB = 4;
+  constexpr int PLANE = 32 * TR_ROWB;            // bytes per plane (32 pixels x 128 channels x 2 B)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * PLANE];
+  unsigned char* A_s = lds;
+  unsigned char* B_s = lds + P * PLANE;
+
+  const int tile = blockIdx.x;
+  const int ci0 = (tile / p.ntile_n) * 128, co0 = (tile % p.ntile_n) * 128;
+  const int tap = blockIdx.y;
+  const int kh = tap / p.KW, kw = tap % p.KW;
+  const int split = blockIdx.z;
+  const int pix_begin = split * p.chunk;
+  const int pix_end = min(pix_begin + p.chunk, p.Mpix);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+  f32x16 acc[TM][TN];
+  acc_zero<TM, TN>(acc);
+  int ea = 0, eb = 0;
+  if constexpr (HALF) {
+    ea = scale_exp_from_amax(*p.amax_x);
+    eb = scale_exp_from_amax(*p.amax_dy);
+  }
+  const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  f32x4 ra[NPA], rb[NPB];
+  auto issue_loads = [&](int pix0) {
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int pi = tid + 256 * j;
+      const int row = pi >> 5, c4 = pi & 31;
+      const unsigned pix = (unsigned)(pix0 + row);
+      const unsigned t = __umulhi(pix, p.magic_wo);
+      const int wo = (int)(pix - t * (unsigned)p.Wo);
+      const unsigned b = __umulhi(t, p.magic_ho);
+      const int ho = (int)(t - b * (unsigned)p.Ho);
+      const int yy = ho * p.stride - p.pad_t + kh, xx = wo * p.stride - p.pad_l + kw;
+      const unsigned bad = (unsigned)((int)pix >= pix_end) | (unsigned)((unsigned)yy >= (unsigned)p.Hi) |
+                           (unsigned)((unsigned)xx >= (unsigned)p.Wi);
+      const unsigned off = (unsigned)((((int)b * p.Hi + yy) * p.Wi + xx) * p.Cin + ci0 + c4 * 4) * 4u;
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off | ((0u - bad) & 0x80000000u), 0, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const int pi = tid + 256 * j;
+      const int row = pi >> 5, c4 = pi & 31;
+      const int pix = pix0 + row;
+      const unsigned bad = (unsigned)(pix >= pix_end);
+      const unsigned off = (unsigned)(pix * p.Cout + co0 + c4 * 4) * 4u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off | ((0u - bad) & 0x80000000u), 0, 0));
+    }
+  };
+  // 4 floats -> P x (4 sixteen-bit pieces = 8 B)
+  auto split4 = [&](const f32x4& v, float scale, u32x2 (&pl)[P]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float a = v[2 * q], b = v[2 * q + 1];
+      if constexpr (HALF) {
+        a *= scale; b *= scale;
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+        pl[0][q] = __builtin_bit_cast(unsigned, h);
+        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+        pl[1][q] = __builtin_bit_cast(unsigned, l);
+      } else {
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+          const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));
+          pl[pp][q] = pk;
+          if (pp + 1 < P) {
+            a -= __builtin_bit_cast(float, pk << 16);
+            b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+          }
+        }
+      }
+    }
+  };
+
+  issue_loads(pix_begin);
+  // transposing-read lane roles: 16-lane group g -> pixel half h = g >> 1, channel half (g & 1); lane 4q+p of the group
+  // supplies pixel row q (and q+4), channels 4p..4p+3 of the group's 16
+  const int g = lane >> 4, q = (lane >> 2) & 3, pch = lane & 3;
+  for (int pix0 = pix_begin; pix0 < pix_end; pix0 += 32) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int pi = tid + 256 * j;
+      const int row = pi >> 5, c4 = pi & 31;
+      u32x2 pl[P];
+      split4(ra[j], sa, pl);
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x2*>(A_s + pp * PLANE + tr_off(row, c4 >> 1) + (c4 & 1) * 8) = pl[pp];
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const int pi = tid + 256 * j;
+      const int row = pi >> 5, c4 = pi & 31;
+      u32x2 pl[P];
+      split4(rb[j], sb, pl);
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x2*>(B_s + pp * PLANE + tr_off(row, c4 >> 1) + (c4 & 1) * 8) = pl[pp];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_loads(pix0 + 32);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 a[TM][P], b[TN][P];
+      const int r1 = 16 * ks + 8 * (g >> 1) + q, r2 = r1 + 4;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int ch = wm0 + tm * 32 + (g & 1) * 16 + 4 * pch;       // first of this lane's 4 address channels
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+          const u32x2 lo = ds_read_tr16(A_s + pp * PLANE + tr_off(r1, ch >> 3) + (ch & 7) * 2);
+          const u32x2 hi = ds_read_tr16(A_s + pp * PLANE + tr_off(r2, ch >> 3) + (ch & 7) * 2);
+          a[tm][pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int ch = wn0 + tn * 32 + (g & 1) * 16 + 4 * pch;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+          const u32x2 lo = ds_read_tr16(B_s + pp * PLANE + tr_off(r1, ch >> 3) + (ch & 7) * 2);
+          const u32x2 hi = ds_read_tr16(B_s + pp * PLANE + tr_off(r2, ch >> 3) + (ch & 7) * 2);
+          b[tn][pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          f32x16 d = acc[tm][tn];
+          if constexpr (P == 3) {
+            d = mfma16w<HALF>(a[tm][2], b[tn][0], d);
+            d = mfma16w<HALF>(a[tm][0], b[tn][2], d);
+            d = mfma16w<HALF>(a[tm][1], b[tn][1], d);
+          }
+          d = mfma16w<HALF>(a[tm][1], b[tn][0], d);
+          d = mfma16w<HALF>(a[tm][0], b[tn][1], d);
+          d = mfma16w<HALF>(a[tm][0], b[tn][0], d);
+          acc[tm][tn] = d;
+        }
+    }
+  }
+
+  float* o = p.out + ((size_t)split * p.KH * p.KW + tap) * p.Cin * p.Cout;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ci = ci0 + wm0 + tm * 32 + acc_row(rr, lane);
+        const int co = co0 + wn0 + tn * 32 + acc_col(lane);
+        const float v = acc[tm][tn][rr];
+        o[(size_t)ci * p.Cout + co] = HALF ? ldexpf(ldexpf(v, -ea), -eb) : v;
+      }
+}
+
 // out[e] = sum_s slabs[s][e]   (fixed order -> deterministic)
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4, int nsplit) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,7 +598,10 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   else if (pl.bmc == 128 && pl.bnc == 32) SGG_WG(128, 32, 32, 32);
   else if (pl.bmc == 64 && pl.bnc == 128) SGG_WG(64, 128, 32, 64);
   else if (pl.bmc == 128 && pl.bnc == 64) SGG_WG(128, 64, 64, 32);
-  else SGG_WG(128, 128, 64, 64);   // (a variant that splits once at the LDS write into a transposed bf16 image measured 5 % slower)
+  else if (precision == 2) hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, true>), grid, dim3(256), 0, st, p);
+  else if (precision == 3) hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, false>), grid, dim3(256), 0, st, p);
+  else if (precision == 6) hipLaunchKernelGGL((conv_wgrad_tr_kernel<3, false>), grid, dim3(256), 0, st, p);
+  else SGG_WG(128, 128, 64, 64);
 #undef SGG_WG
   SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad");
   if (pl.nsplit > 1) {
