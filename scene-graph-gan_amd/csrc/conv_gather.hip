@@ -366,13 +366,16 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WGM, int WGN, int P, bool WS, bool HALF>
-__global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
+template <int BM, int BN, int WGM, int WGN, int P, bool WS, bool HALF, int BK>
+__global__ __launch_bounds__(256, (P == 2 && BK == 32 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
   static_assert(!HALF || P == 2, "f16 mode uses two pieces");
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int NPA = BM / 64, NPB = (BN + 63) / 64;    // row passes: 64 rows x 4 chunks of 8 k per pass
-  constexpr int ROWB = 64;                              // bytes per plane row (32 bf16)
+  constexpr int CPR = BK / 8;                           // 16-B chunks (8 k) per plane row
+  constexpr int RPP = 256 / CPR;                        // rows staged per pass of the 256 threads
+  constexpr int NPA = BM / RPP, NPB = (BN + RPP - 1) / RPP;
+  constexpr int ROWB = BK * 2;                          // bytes per plane row (BK sixteen-bit pieces)
+  static_assert(BK == 32 || BK == 64, "slab depth");
   static_assert(WGM * WGN == 4 && BM % 64 == 0 && BN % 32 == 0 && (P == 2 || P == 3), "tile");
 
   __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * ROWB * P + BM * 4];
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
-  const int chunk = tid & 3, prow = tid >> 2;           // this thread stages k = 8*chunk .. 8*chunk+7 of rows prow + 64*j
+  const int chunk = tid % CPR, prow = tid / CPR;        // this thread stages k = 8*chunk .. 8*chunk+7 of rows prow + RPP*j
 
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, src_bytes, 0x00020000);
   // WS: weights arrive pre-split (P bf16 planes, written once per optimiser step) - no split VALU for the B operand
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
   int a_ys[NPA], a_xs[NPA], a_off[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
-    const int m = m0 + prow + 64 * j;
+    const int m = m0 + prow + RPP * j;
     if (m < c.M) {
       const int x = m % c.Wm;
       const int t = m / c.Wm;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
   f32x16 acc[TM][TN];
   acc_zero<TM, TN>(acc);
 
-  const int n_iters = c.nth * c.ntw * (p.C >> 5);
+  const int n_iters = c.nth * c.ntw * (p.C / BK);
   int s_th = 0, s_tw = 0, s_c0 = 0, s_it = 0;
   f32x4 ra[NPA][2], rb[NPB][WS ? P : 2];
   auto issue_loads = [&]() {
@@ -458,19 +461,19 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
     }
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
-      const unsigned deadb = dead | (unsigned)(prow + 64 * j >= BN);     // (BN = 32: half of the threads stage no weights)
+      const unsigned deadb = dead | (unsigned)(prow + RPP * j >= BN);    // (BN < RPP: some threads stage no weights)
       if constexpr (WS) {
-        const unsigned off = ((unsigned)(woff + 64 * j * p.C) * 2u) | ((0u - deadb) & SGG_OOB);
+        const unsigned off = ((unsigned)(woff + RPP * j * p.C) * 2u) | ((0u - deadb) & SGG_OOB);
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) rb[j][pp] = buf_load4(rs_w, off + pp * w_plane_bytes);
       } else {
-        const unsigned off = ((unsigned)(woff + 64 * j * p.C) * 4u) | ((0u - deadb) & SGG_OOB);
+        const unsigned off = ((unsigned)(woff + RPP * j * p.C) * 4u) | ((0u - deadb) & SGG_OOB);
         rb[j][0] = buf_load4(rs_w, off);
         rb[j][1] = buf_load4(rs_w, off + 16u);
       }
     }
     ++s_it;
-    s_c0 += 32;
+    s_c0 += BK;
     const bool wrap_c = s_c0 >= p.C;
     s_c0 = wrap_c ? 0 : s_c0;
     s_tw += wrap_c ? 1 : 0;
@@ -479,7 +482,8 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
     s_th += wrap_w ? 1 : 0;
   };
   // swizzled byte offset of (row, logical 16-B chunk q) inside one plane
-  auto sw = [](int row, int q) { return row * ROWB + ((q ^ ((row >> 2) & 3)) << 4); };
+  // (64-B rows: 4 rows share a 256-B bank row -> XOR with (row>>2)&3; 128-B rows: 2 rows -> XOR with (row>>1)&7)
+  auto sw = [](int row, int q) { return row * ROWB + ((q ^ (BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7))) << 4); };
 
   issue_loads();
   for (int it = 0; it < n_iters; ++it) {
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
       u32x4 pl[P];
       split8<P, HALF>(ra[j][0], ra[j][1], sa, pl);
 #pragma unroll
-      for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(A_s + pp * BM * ROWB + sw(prow + 64 * j, chunk)) = pl[pp];
+      for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(A_s + pp * BM * ROWB + sw(prow + RPP * j, chunk)) = pl[pp];
     }
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
@@ -501,9 +505,9 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
       } else {
         split8<P, HALF>(rb[j][0], rb[j][1], sb, pl);
       }
-      if (prow + 64 * j < BN) {
+      if (prow + RPP * j < BN) {
 #pragma unroll
-        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(B_s + pp * BN * ROWB + sw(prow + 64 * j, chunk)) = pl[pp];
+        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(B_s + pp * BN * ROWB + sw(prow + RPP * j, chunk)) = pl[pp];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256, (P == 2 ? 3 : 2)) void conv_gather_bf16s_kerne
     __builtin_amdgcn_sched_barrier(0);
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       u32x4 a[TM][P], b[TN][P];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
@@ -649,7 +653,7 @@ static void launch_gather3(const GatherParams& p, hipStream_t st) {
   hipLaunchKernelGGL((conv_gather3_kernel<BM, BN, WGM, WGN, BK>), grid, dim3(256), 0, st, q, src_bytes);
 }
 
-template <int BM, int BN, int WGM, int WGN, int P, bool HALF>
+template <int BM, int BN, int WGM, int WGN, int P, bool HALF, int BK = 32>
 static void launch_gather_bf16s(const GatherParams& p, hipStream_t st) {
   int maxwg = 0;
   GatherParams q = p;
@@ -661,9 +665,9 @@ static void launch_gather_bf16s(const GatherParams& p, hipStream_t st) {
   const unsigned src_bytes = (unsigned)((size_t)q.B * q.Hs * q.Ws * q.C * sizeof(float));
   dim3 grid(maxwg, q.ncls, 1);
   if (q.w_split && (size_t)(q.w_bytes / 2) * P < 0x80000000ull)
-    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, true, HALF>), grid, dim3(256), 0, st, q, src_bytes);
+    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, true, HALF, BK>), grid, dim3(256), 0, st, q, src_bytes);
   else
-    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, false, HALF>), grid, dim3(256), 0, st, q, src_bytes);
+    hipLaunchKernelGGL((conv_gather_bf16s_kernel<BM, BN, WGM, WGN, P, false, HALF, BK>), grid, dim3(256), 0, st, q, src_bytes);
 }
 
 // precision: 0 = native f32 MFMA; 2 = scaled f16 pieces, 3 products; 3 / 6 = bf16 pieces, 3 / 6 products
@@ -676,6 +680,7 @@ static int dispatch_gather(const GatherParams& p, hipStream_t st, int precision)
     else if (precision == 3) launch_gather_bf16s<BM, BN, WGM, WGN, 2, false>(p, st);    \
     else launch_gather_bf16s<BM, BN, WGM, WGN, 3, false>(p, st);                        \
   } while (0)
+    // (64-deep slabs, BK = 64: 2 instead of 3 waves per SIMD, measured 3 % slower in every mode)
     if (p.N % 128 == 0) SGG_GB(128, 128, 2, 2);
     else if (p.N % 64 == 0) SGG_GB(256, 64, 4, 1);
     else SGG_GB(256, 32, 4, 1);
