@@ -367,7 +367,7 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 
 }
 
 template <int BM, int BN, int WGM, int WGN, int P, bool WS, bool HALF, int BK>
-__global__ __launch_bounds__(256, (P == 2 && BK == 32 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
+__global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
   static_assert(!HALF || P == 2, "f16 mode uses two pieces");
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -681,6 +681,7 @@ static int dispatch_gather(const GatherParams& p, hipStream_t st, int precision)
     else launch_gather_bf16s<BM, BN, WGM, WGN, 3, false>(p, st);                        \
   } while (0)
     // (64-deep slabs, BK = 64: 2 instead of 3 waves per SIMD, measured 3 % slower in every mode)
+    // (a 128 x 256 tile for N >= 256: 242 VGPRs, 2 waves per SIMD, measured +-3 % - not dispatched)
     if (p.N % 128 == 0) SGG_GB(128, 128, 2, 2);
     else if (p.N % 64 == 0) SGG_GB(256, 64, 4, 1);
     else SGG_GB(256, 32, 4, 1);
