@@ -43,7 +43,10 @@ int sgg_conv_split_weights(const float* in, void* out, long long n, int precisio
 int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; zero it first */, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
-                        const float* amax_x, const float* amax_w, void* stream);
+                        const float* amax_x, const float* amax_w, float* tile_stats, void* stream);
+/* tile_stats (optional): the epilogue also writes (count, mean, M2) of every output tile, [B][n][3] with
+ * n = sgg_conv2d_nhwc_fwd_tile_stats(...) > 0; pass them to sgg_layernorm_hwc_elu_fwd to skip its statistics pass. */
+int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int precision);
 /* Conv2DBackpropInput: dx from dy and the HWIO kernel */
 int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
@@ -61,7 +64,8 @@ int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B
 size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C);
 /* amax_out (optional): device word atomically max-ed with max|output| (the consumer convolution's f16 scaling) */
 int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
-                              float* amax_out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+                              float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
+                              void* workspace, size_t workspace_bytes, void* stream);
 int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
                               const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
                               float* amax_out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);

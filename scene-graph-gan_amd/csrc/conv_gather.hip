@@ -37,6 +37,8 @@ struct GatherParams {
   int N;             // output channels, N % 32 == 0
   int Ho, Wo;        // full output grid
   int sy, sx, dy, dx, osy, osx, KW;
+  float* tile_stats;   // optional (forward, HW % BM == 0): per output tile (count, mean, M2) of y for the following LayerNorm
+  int hw;              // output pixels per sample (tile_stats indexing)
   int ncls;
   unsigned w_bytes;    // size of the weight tensor (bounds the buffer descriptor of the v2 kernel)
   GatherClass cls[4];
@@ -546,6 +548,8 @@ __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) voi
     }
   }
 
+  // ---- epilogue: unscale, + bias, store; optionally the tile's LayerNorm partial statistics ---------------
+  float lsum = 0.f;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + wn0 + tn * 32 + acc_col(lane);
@@ -556,8 +560,42 @@ __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) voi
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + tm * 32 + acc_row(r, lane);
         const int off = out_off_s[row];
-        if (off >= 0) p.out[(size_t)off + n] = HALF ? ldexpf(ldexpf(acc[tm][tn][r], -ea), -eb) + bv : acc[tm][tn][r] + bv;
+        const float v = HALF ? ldexpf(ldexpf(acc[tm][tn][r], -ea), -eb) + bv : acc[tm][tn][r] + bv;
+        acc[tm][tn][r] = v;
+        lsum += v;
+        if (off >= 0) p.out[(size_t)off + n] = v;
       }
+    }
+  }
+  if (p.tile_stats) {
+    // (count, mean, M2) of the BM x BN outputs of this tile; the tile lies inside one sample (host guarantees hw % BM == 0).
+    // Merged per sample with Chan's formula by ln_apply_elu_kernel -> the separate statistics pass over y is skipped.
+    float* red = reinterpret_cast<float*>(lds);          // the operand planes are dead now
+    __syncthreads();
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    const float mean_t = (red[0] + red[1] + red[2] + red[3]) * (1.f / (float)(BM * BN));
+    float q = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[tm][tn][r] - mean_t;
+          q += d * d;
+        }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    if (tid == 0) {
+      const int b = m0 / p.hw, t_in = (m0 - b * p.hw) / BM;
+      const int tps = p.hw / BM;
+      float* o = p.tile_stats + ((size_t)(b * tps + t_in) * ntiles_n + nt) * 3;
+      o[0] = (float)(BM * BN);
+      o[1] = mean_t;
+      o[2] = red[4] + red[5] + red[6] + red[7];
     }
   }
 }
@@ -739,10 +777,20 @@ extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, in
   return SGG_OK;
 }
 
+// Number of (count, mean, M2) triples per sample the forward conv can emit for the following LayerNorm
+// (0 = not available for this shape / precision: use the LayerNorm's own statistics pass).
+extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int precision) {
+  if (precision == 0 || Cin == 3 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
+  const int bm = (Cout % 128 == 0) ? 128 : 256;
+  const int bn = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0 ? 64 : 32);
+  if ((Ho * Wo) % bm != 0) return 0;
+  return (Ho * Wo / bm) * (Cout / bn);
+}
+
 // Forward. `w` is the HWIO kernel for Cin == 3 and the HWOI transpose (sgg_hwio_to_hwoi) otherwise.
 extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi,
                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
-                                   int precision, const float* amax_x, const float* amax_w, void* stream) {
+                                   int precision, const float* amax_x, const float* amax_w, float* tile_stats, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
   SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 2, 3 or 6");
   SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 2 needs the amax words");
@@ -764,6 +812,13 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
   GatherParams p;
   p.src = x; p.wm = w; p.bias = bias; p.out = y; p.w_split = (precision != 0) ? w_split : nullptr;
   p.amax_src = amax_x; p.amax_w = amax_w;
+  p.hw = Ho * Wo;
+  p.tile_stats = nullptr;
+  if (tile_stats && precision != 0) {
+    const int bm = (Cout % 128 == 0) ? 128 : 256;
+    SGG_CHECK_ARG((Ho * Wo) % bm == 0, "sgg_conv2d_nhwc_fwd: tile_stats needs Ho*Wo %% %d == 0 (see sgg_conv2d_nhwc_fwd_tile_stats)", bm);
+    p.tile_stats = tile_stats;
+  }
   p.B = B; p.Hs = Hi; p.Ws = Wi; p.C = Cin; p.N = Cout; p.Ho = Ho; p.Wo = Wo;
   p.sy = stride; p.sx = stride; p.dy = 1; p.dx = 1; p.osy = 1; p.osx = 1; p.KW = KW;
   p.ncls = 1;
@@ -790,6 +845,8 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
   GatherParams p;
   p.src = dy; p.wm = w; p.bias = nullptr; p.out = dx; p.w_split = (precision != 0) ? w_split : nullptr;
   p.amax_src = amax_dy; p.amax_w = amax_w;
+  p.hw = Hi * Wi;
+  p.tile_stats = nullptr;
   p.B = B; p.Hs = Ho; p.Ws = Wo; p.C = Cout; p.N = Cin; p.Ho = Hi; p.Wo = Wi;
   p.sy = 1; p.sx = 1; p.dy = -1; p.dx = -1; p.osy = stride; p.osx = stride; p.KW = KW;
   p.ncls = stride * stride;

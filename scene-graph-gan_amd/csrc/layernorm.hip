@@ -319,13 +319,22 @@ static int ln_check(const char* name, int B, int HW, int C, size_t ws_bytes, voi
   return SGG_OK;
 }
 
+// tile_stats / n_tile_stats (optional): [B][n_tile_stats][3] (count, mean, M2) partials of y already produced by the
+// convolution's epilogue (sgg_conv2d_nhwc_fwd); the statistics pass over y is then skipped.
 extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
-                                         float* amax_out, int B, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+                                         float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
+                                         void* ws, size_t ws_bytes, void* stream) {
   SGG_CHECK_ARG(y && gamma && beta && a && stats, "sgg_layernorm_hwc_elu_fwd: null pointer");
   int rc = ln_check("sgg_layernorm_hwc_elu_fwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
   const LnGeom g = ln_geom(B, HW, C);
   hipStream_t st = (hipStream_t)stream;
+  if (tile_stats && n_tile_stats > 0) {
+    hipLaunchKernelGGL(ln_apply_elu_kernel, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, tile_stats, a, stats, g.N, C,
+                       n_tile_stats, g.cpg, amax_out);
+    SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_fwd");
+    return SGG_OK;
+  }
   float* part = (float*)ws;
   hipLaunchKernelGGL(ln_stats_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg);
   hipLaunchKernelGGL(ln_apply_elu_kernel, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)part, a, stats, g.N,

@@ -30,12 +30,13 @@ SIGNATURES = {
     "sgg_hwio_to_hwoi": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sgg_conv_split_weights": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
     "sgg_absmax": (_i, [_vp, _ll, _vp, _vp]),
-    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
+    "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 5),
     "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
     "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 6 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 4 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 3 + [_vp, _sz, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -212,7 +213,11 @@ class HipKernels:
         self._check(self.lib.sgg_conv_split_weights(_p(w), _p(out), w.numel(), self.conv_precision, _p(amax), self._stream()),
                     "sgg_conv_split_weights")
 
-    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None):
+    def conv_tile_stats_count(self, y_shape, cin):
+        """(count, mean, M2) triples per sample the forward conv emits for this output shape in the current mode (0: none)."""
+        return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], self.conv_precision)
+
+    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
         self._dev(x, w_fwd, bias, y)
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
@@ -222,8 +227,8 @@ class HipKernels:
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
-            _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, _p(amax_x), _p(amax_w), self._stream())),
-            "sgg_conv2d_nhwc_fwd")
+            _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, _p(amax_x), _p(amax_w), _p(tile_stats),
+            self._stream())), "sgg_conv2d_nhwc_fwd")
 
     def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None):
         self._dev(dy, w_hwio, dx)
@@ -248,12 +253,15 @@ class HipKernels:
             _p(x), _p(dy), _p(dw), *d, self.conv_precision, _p(amax_x), _p(amax_dy), _p(ws), ws.numel(), self._stream())),
             "sgg_conv2d_nhwc_wgrad")
 
-    def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None):
-        self._dev(y, gamma, beta, a, stats, amax_out)
+    def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None, tile_stats=None):
+        """tile_stats [B, n, 3]: per-tile (count, mean, M2) written by conv_fwd's epilogue (skips the statistics pass)."""
+        self._dev(y, gamma, beta, a, stats, amax_out, tile_stats)
         B, H, W, C = y.shape
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
         ws = self.workspace(need)
-        self._check(self.lib.sgg_layernorm_hwc_elu_fwd(_p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), B, H * W, C, _p(ws),
+        nts = 0 if tile_stats is None else tile_stats.shape[1]
+        self._check(self.lib.sgg_layernorm_hwc_elu_fwd(_p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), _p(tile_stats), nts,
+                                                       B, H * W, C, _p(ws),
                                                        ws.numel(), self._stream()), "sgg_layernorm_hwc_elu_fwd")
 
     def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None):

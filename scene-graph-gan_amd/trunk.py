@@ -42,6 +42,12 @@ class Trunk:
             if cin != 3 and getattr(K, "conv_precision", 0) and hasattr(K, "split_weights"):
                 lay["ws_fwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
                 lay["ws_bwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
+            lay["tstats"] = None
+            if has_ln and hasattr(K, "conv_tile_stats_count"):
+                nts = K.conv_tile_stats_count((B, ho, wo, cout), cin)
+                if nts > 0:     # the conv epilogue emits the LayerNorm partial statistics for this shape
+                    lay["tstats"] = torch.zeros((B, nts, 3), device=dev, dtype=dt)
+                    lay["tstats_mode"] = K.conv_precision
             if has_ln:
                 lay["gamma"], lay["beta"] = p[ln_name(i) + "/gamma"], p[ln_name(i) + "/beta"]
                 lay["ggamma"], lay["gbeta"] = g[ln_name(i) + "/gamma"], g[ln_name(i) + "/beta"]
@@ -89,13 +95,14 @@ class Trunk:
             K.fill(self.amax[0], 0.0)
         for j, lay in enumerate(self.layers):
             ws = lay["ws_fwd"] if (lay["ws_fwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
-            if ws is not None or self._f16():
-                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j))
+            ts = lay["tstats"] if (lay["tstats"] is not None and lay.get("tstats_mode") == getattr(K, "conv_precision", 0)) else None
+            if ws is not None or self._f16() or ts is not None:
+                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j), ts)
             else:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             if lay["has_ln"]:
-                if self._f16():
-                    K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], self._am(0, j))
+                if self._f16() or ts is not None:
+                    K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], self._am(0, j), ts)
                 else:
                     K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"])
                 x = lay["a"]

@@ -345,3 +345,33 @@ def test_errors_are_loud(hip):
         hip.conv_fwd(x, w, w, torch.zeros(32, device="cuda"), y, 1)
     with pytest.raises(SggError):
         hip.fill(torch.zeros(4), 1.0)                    # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("cout", [32, 64, 128])
+def test_conv_epilogue_layernorm_stats(hip, ref, cout):
+    """The split conv kernels can emit per-tile (count, mean, M2) of their output; LayerNorm merged from those
+    must equal LayerNorm with its own statistics pass (and the fp64 reference)."""
+    if hip.conv_precision == 0:
+        pytest.skip("native f32 kernels do not emit tile statistics")
+    B, H, W, Ci, k, s = 3, 16, 16, 64, 3, 1
+    x, w, b = rnd((B, H, W, Ci), 90), rnd((k, k, Ci, cout), 91, 0.05), rnd((cout,), 92, 0.5)
+    gamma, beta = 1.0 + rnd((cout,), 93, 0.2), rnd((cout,), 94, 0.2)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    wf = torch.empty((k, k, cout, Ci), device="cuda")
+    hip.hwio_to_hwoi(wd, wf)
+    nts = hip.conv_tile_stats_count((B, H, W, cout), Ci)
+    assert nts > 0
+    ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+    y = torch.empty((B, H, W, cout), device="cuda")
+    hip.conv_fwd(xd, wd, wf, bd, y, s, tile_stats=ts)
+    a1, a2 = torch.empty_like(y), torch.empty_like(y)
+    st1, st2 = torch.empty((B, 2), device="cuda"), torch.empty((B, 2), device="cuda")
+    hip.ln_elu_fwd(y, dev(gamma), dev(beta), a1, st1, tile_stats=ts)
+    hip.ln_elu_fwd(y, dev(gamma), dev(beta), a2, st2)
+    close(st1, st2.cpu(), rtol=1e-6, what="stats from conv epilogue vs statistics pass")
+    close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+    y_ref = torch.empty((B, H, W, cout), dtype=torch.float64)
+    ref.conv_fwd(x.double(), w.double(), None, b.double(), y_ref, s)
+    a_ref, st_ref = torch.empty_like(y_ref), torch.empty((B, 2), dtype=torch.float64)
+    ref.ln_elu_fwd(y_ref, gamma.double(), beta.double(), a_ref, st_ref)
+    close(a1, a_ref, rtol=5e-5, what="conv + LN vs fp64")
