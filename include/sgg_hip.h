@@ -41,15 +41,21 @@ int sgg_hwio_to_hwoi(const float* w_hwio, float* w_hwoi, int taps, int cin, int 
  * saves the per-workgroup split of the weight operand in the split-bf16 modes. */
 int sgg_conv_split_weights(const float* in, void* out, long long n, int precision, const float* amax, void* stream);
 int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; zero it first */, void* stream);
+/* Halo-resident kernel for the 3x3 stride-1 layers (generator_with_attention.py:31-57: conv1_2, conv2_1..2_4, conv3_1,
+ * conv3_2) in precision 2 / 3: sgg_conv_wsplit_layout returns 1 where it applies (H % 8 == W % 8 == 0); the pre-split weights
+ * must then be in MFMA fragment order (sgg_conv_split_weights_frag over the [taps][N][C] tensor: the HWOI transpose for the
+ * forward, the HWIO kernel for dgrad) and w_split_layout = 1 is passed to sgg_conv2d_nhwc_fwd / _dgrad.  Layout 0 = planes. */
+int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);
+int sgg_conv_split_weights_frag(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
-                        int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                        int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
                         const float* amax_x, const float* amax_w, float* tile_stats, void* stream);
 /* tile_stats (optional): the epilogue also writes (count, mean, M2) of every output tile, [B][n][3] with
  * n = sgg_conv2d_nhwc_fwd_tile_stats(...) > 0; pass them to sgg_layernorm_hwc_elu_fwd to skip its statistics pass. */
-int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int precision);
+int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision, int w_split_layout);
 /* Conv2DBackpropInput: dx from dy and the HWIO kernel */
 int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
-                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
                           const float* amax_dy, const float* amax_w, void* stream);
 /* Conv2DBackpropFilter: dw (HWIO) from x and dy */
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);

@@ -13,7 +13,8 @@
 // Tiling: workgroup = 256 threads = 4 waves; tile BM x BN x 32(k); A (gathered pixels) and B (weights) are
 // staged global -> registers -> LDS (KC layout, see mma_f32.h) with the next slab's global loads in flight
 // while the current slab is contracted (register prefetch, one LDS buffer).
-#include "mma_f32.h"
+#include "split16.h"
+#include "conv_halo.h"
 #include <stdlib.h>
 
 struct GatherClass {
@@ -177,12 +178,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherParams p) {
 //     after the second barrier and in flight during the whole MFMA burst (register prefetch, one LDS buffer of
 //     (128+128) x 68 floats = 69.6 KB -> two workgroups per CU).
 // ---------------------------------------------------------------------------------------------------
-#define SGG_OOB 0x80000000u
 #define SGG_LDK64 68
-
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
-}
 
 template <int BM, int BN, int WGM, int WGN, int BK>
 __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_gather3_kernel(GatherParams p, unsigned src_bytes) {
@@ -319,55 +315,6 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_gather3_kernel(G
 // LDS planes are [row][32 k] bf16 (64 B rows) with the 16-B chunk index XOR-swizzled by (row >> 2) & 3, which makes
 // both the ds_write_b128 of the split pieces and the ds_read_b128 of the MFMA fragments conflict free.
 // ---------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
-}
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-
-// 8 consecutive floats -> P planes of 8 sixteen-bit pieces (16 B each), x*scale = x0 + x1 (+ x2).
-//   HALF = false: bf16 pieces (RNE), scale unused.   HALF = true: fp16 pieces (P = 2) of the pre-scaled value; the scale
-//   is a power of two chosen from the tensor's max|x| so that |x*scale| <= 2^14 (no overflow, and the second piece
-//   only reaches fp16 subnormals 38 binades below the tensor's maximum): 22 significant bits in two pieces.
-template <int P, bool HALF>
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float scale, u32x4 (&pl)[P]) {
-  float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float a = x[2 * q], b = x[2 * q + 1];
-    if constexpr (HALF) {
-      a *= scale; b *= scale;
-      const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-      pl[0][q] = __builtin_bit_cast(unsigned, h);
-      const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
-      pl[1][q] = __builtin_bit_cast(unsigned, l);
-    } else {
-#pragma unroll
-      for (int pp = 0; pp < P; ++pp) {
-        const unsigned pk = cvt_pk_bf16(a, b);
-        pl[pp][q] = pk;
-        if (pp + 1 < P) {
-          a -= __builtin_bit_cast(float, pk << 16);
-          b -= __builtin_bit_cast(float, pk & 0xffff0000u);
-        }
-      }
-    }
-  }
-}
-
-template <bool HALF>
-__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 c) {
-  if constexpr (HALF)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 template <int BM, int BN, int WGM, int WGN, int P, bool WS, bool HALF, int BK>
 __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) void conv_gather_bf16s_kernel(GatherParams p, unsigned src_bytes) {
   static_assert(!HALF || P == 2, "f16 mode uses two pieces");
@@ -779,8 +726,13 @@ extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, in
 
 // Number of (count, mean, M2) triples per sample the forward conv can emit for the following LayerNorm
 // (0 = not available for this shape / precision: use the LayerNorm's own statistics pass).
-extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int precision) {
+extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision,
+                                              int w_split_layout) {
   if (precision == 0 || Cin == 3 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
+  if (w_split_layout == 1) {
+    if (!sgg_halo_applicable(KH, KW, stride, Ho, Wo, Cin, Cout, precision)) return 0;
+    return (Ho * Wo / 64) * (Cout / sgg_halo_stats_cols(Cout));
+  }
   const int bm = (Cout % 128 == 0) ? 128 : 256;
   const int bn = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0 ? 64 : 32);
   if ((Ho * Wo) % bm != 0) return 0;
@@ -790,7 +742,8 @@ extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout,
 // Forward. `w` is the HWIO kernel for Cin == 3 and the HWOI transpose (sgg_hwio_to_hwoi) otherwise.
 extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi,
                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
-                                   int precision, const float* amax_x, const float* amax_w, float* tile_stats, void* stream) {
+                                   int precision, int w_split_layout, const float* amax_x, const float* amax_w, float* tile_stats,
+                                   void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
   SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 2, 3 or 6");
   SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 2 needs the amax words");
@@ -809,6 +762,19 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     return SGG_OK;
   }
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_fwd: Cin and Cout must be multiples of 32 (or Cin == 3)");
+  if (w_split_layout == 1) {        // halo-resident 3x3 stride-1 kernel, weights in MFMA fragment order
+    SGG_CHECK_ARG(w_split && sgg_halo_applicable(KH, KW, stride, Hi, Wi, Cin, Cout, precision) && pad_t == 1 && pad_l == 1,
+                  "sgg_conv2d_nhwc_fwd: w_split_layout 1 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
+    HaloParams h;
+    h.src = x; h.wfrag = w_split; h.bias = bias; h.out = y; h.amax_src = amax_x; h.amax_w = amax_w; h.tile_stats = tile_stats;
+    h.B = B; h.H = Hi; h.W = Wi; h.C = Cin; h.N = Cout; h.bh = Hi / 8; h.bw = Wi / 8; h.nblk = B * h.bh * h.bw; h.flip = 0;
+    h.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
+    h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
+    SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
+    sgg_halo_launch(h, precision, st);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(halo)");
+    return SGG_OK;
+  }
   GatherParams p;
   p.src = x; p.wm = w; p.bias = bias; p.out = y; p.w_split = (precision != 0) ? w_split : nullptr;
   p.amax_src = amax_x; p.amax_w = amax_w;
@@ -834,7 +800,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
 // dgrad: dx[B,Hi,Wi,Cin] = conv-transpose of dy[B,Ho,Wo,Cout] with the HWIO kernel w (no bias).
 extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
-                                     const float* amax_dy, const float* amax_w, void* stream) {
+                                     int w_split_layout, const float* amax_dy, const float* amax_w, void* stream) {
   SGG_CHECK_ARG(dy && w && dx, "sgg_conv2d_nhwc_dgrad: null pointer");
   SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_dgrad: precision must be 0, 2, 3 or 6");
   SGG_CHECK_ARG(precision != 2 || (amax_dy && amax_w), "sgg_conv2d_nhwc_dgrad: precision 2 needs the amax words");
@@ -842,6 +808,20 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_dgrad: Cin and Cout must be multiples of 32");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
                 "sgg_conv2d_nhwc_dgrad: tensor exceeds 2^31 elements");
+  if (w_split_layout == 1) {        // halo-resident 3x3 stride-1 kernel: dx = correlation of dy with the mirrored taps
+    SGG_CHECK_ARG(w_split && sgg_halo_applicable(KH, KW, stride, Hi, Wi, Cout, Cin, precision) && pad_t == 1 && pad_l == 1 &&
+                      Ho == Hi && Wo == Wi,
+                  "sgg_conv2d_nhwc_dgrad: w_split_layout 1 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
+    SGG_CHECK_ARG((size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_dgrad: dy exceeds 2 GiB");
+    HaloParams h;
+    h.src = dy; h.wfrag = w_split; h.bias = nullptr; h.out = dx; h.amax_src = amax_dy; h.amax_w = amax_w; h.tile_stats = nullptr;
+    h.B = B; h.H = Hi; h.W = Wi; h.C = Cout; h.N = Cin; h.bh = Hi / 8; h.bw = Wi / 8; h.nblk = B * h.bh * h.bw; h.flip = 1;
+    h.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
+    h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
+    sgg_halo_launch(h, precision, (hipStream_t)stream);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(halo)");
+    return SGG_OK;
+  }
   GatherParams p;
   p.src = dy; p.wm = w; p.bias = nullptr; p.out = dx; p.w_split = (precision != 0) ? w_split : nullptr;
   p.amax_src = amax_dy; p.amax_w = amax_w;

@@ -1,0 +1,24 @@
+// Halo-resident 3x3 stride-1 convolution (split 16-bit modes): internal interface between conv_halo.hip (kernel, launch)
+// and conv_gather.hip (the sgg_conv2d_nhwc_fwd / _dgrad entry points that dispatch to it).
+#pragma once
+#include "sgg_common.h"
+
+struct HaloParams {
+  const float* src;       // [B, H, W, C] f32 NHWC (forward: x; dgrad: dy)
+  const void* wfrag;      // weights as MFMA B fragments (sgg_conv_split_weights_frag)
+  const float* bias;      // may be null
+  float* out;             // [B, H, W, N]
+  const float* amax_src;  // precision 2: device words with max|src| and max|w|
+  const float* amax_w;
+  float* tile_stats;      // optional: per (8x8 block, wave column range) (count, mean, M2) for the following LayerNorm
+  int B, H, W, C, N;
+  int bh, bw, nblk;       // 8x8 blocks per image (rows, cols) and in total
+  int flip;               // 0: forward (correlation); 1: dgrad (taps mirrored)
+  unsigned src_bytes, w_bytes;
+};
+
+// 1 if the halo kernel serves a 3x3 / stride-1 convolution over an H x W grid in this precision
+int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, int precision);
+// columns covered by one (count, mean, M2) partial of the halo kernel for N output channels
+int sgg_halo_stats_cols(int N);
+void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st);

@@ -1,0 +1,61 @@
+// Shared pieces of the split 16-bit convolution kernels (gfx950): raw buffer loads with an out-of-range marker,
+// the f32 -> 16-bit piece split and the 32x32x16 MFMA wrappers.  Used by conv_gather.hip and conv_halo.hip.
+#pragma once
+#include "mma_f32.h"
+
+#define SGG_OOB 0x80000000u
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+// 8 consecutive floats -> P planes of 8 sixteen-bit pieces (16 B each), x*scale = x0 + x1 (+ x2).
+//   HALF = false: bf16 pieces (RNE), scale unused.   HALF = true: fp16 pieces (P = 2) of the pre-scaled value; the scale
+//   is a power of two chosen from the tensor's max|x| so that |x*scale| <= 2^14 (no overflow, and the second piece
+//   only reaches fp16 subnormals 38 binades below the tensor's maximum): 22 significant bits in two pieces.
+template <int P, bool HALF>
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float scale, u32x4 (&pl)[P]) {
+  float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a = x[2 * q], b = x[2 * q + 1];
+    if constexpr (HALF) {
+      a *= scale; b *= scale;
+      const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+      pl[0][q] = __builtin_bit_cast(unsigned, h);
+      const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+      pl[1][q] = __builtin_bit_cast(unsigned, l);
+    } else {
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) {
+        const unsigned pk = cvt_pk_bf16(a, b);
+        pl[pp][q] = pk;
+        if (pp + 1 < P) {
+          a -= __builtin_bit_cast(float, pk << 16);
+          b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+        }
+      }
+    }
+  }
+}
+
+template <bool HALF>
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 c) {
+  if constexpr (HALF)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+

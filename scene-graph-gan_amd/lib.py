@@ -30,9 +30,11 @@ SIGNATURES = {
     "sgg_hwio_to_hwoi": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sgg_conv_split_weights": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
     "sgg_absmax": (_i, [_vp, _ll, _vp, _vp]),
-    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
-    "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 5),
-    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp]),
+    "sgg_conv_wsplit_layout": (_i, [_i] * 8),
+    "sgg_conv_split_weights_frag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp]),
+    "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
+    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
     "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -122,6 +124,7 @@ class HipKernels:
         #   0           native f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 fmaf chain);
         #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance).
         self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
+        self.conv_halo = os.environ.get("SGG_CONV_HALO", "1") != "0"
         assert self.conv_precision in (0, 2, 3, 6)
         self._amax_scratch = torch.zeros(8, dtype=torch.float32, device=self.device)
 
@@ -206,39 +209,59 @@ class HipKernels:
         self.absmax(t, w)
         return w
 
-    def split_weights(self, w, out, amax=None):
-        """w fp32 (n % 8 == 0) -> out int16 [P, n] sixteen-bit planes for the current conv precision."""
+    def conv_wsplit_layout(self, k, stride, H, W, cin, cout):
+        """Layout the conv entry points want for the pre-split weights of this layer: 0 = planes, 1 = MFMA fragment order
+        (halo-resident 3x3 stride-1 kernel; SGG_CONV_HALO=0 keeps every layer on the gather kernel)."""
+        if not self.conv_halo:
+            return 0
+        return self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
+
+    def split_weights(self, w, out, amax=None, layout=0):
+        """w fp32 [kh, kw, N, C] -> out int16 [P, n] sixteen-bit planes (layout 0) or MFMA B fragments (layout 1)."""
         self._dev(w, out, amax)
         amax = self._amax_or_compute(w, amax, 2)
+        if layout == 1:
+            kh, kw, n, c = w.shape
+            self._check(self.lib.sgg_conv_split_weights_frag(_p(w), _p(out), kh * kw, n, c, self.conv_precision, _p(amax),
+                                                             self._stream()), "sgg_conv_split_weights_frag")
+            return
         self._check(self.lib.sgg_conv_split_weights(_p(w), _p(out), w.numel(), self.conv_precision, _p(amax), self._stream()),
                     "sgg_conv_split_weights")
 
-    def conv_tile_stats_count(self, y_shape, cin):
+    def conv_tile_stats_count(self, y_shape, cin, k=0, stride=0, layout=0):
         """(count, mean, M2) triples per sample the forward conv emits for this output shape in the current mode (0: none)."""
-        return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], self.conv_precision)
+        return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], k, k, stride, self.conv_precision,
+                                                       layout)
 
-    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None):
+    def halo_symbol(self, n_out):
+        tile = "2,128,2,2" if n_out % 128 == 0 else ("4,64,4,1" if n_out % 64 == 0 else "4,32,4,1")
+        return "conv_halo3_kernel<%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
+                                                "true" if n_out % 128 == 0 else "false")
+
+    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
         self._dev(x, w_fwd, bias, y)
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else self.gather_symbol(d[6], w_split is not None)
+        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else (self.halo_symbol(d[6]) if w_split_layout == 1 else
+                                                             self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
-            _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, _p(amax_x), _p(amax_w), _p(tile_stats),
-            self._stream())), "sgg_conv2d_nhwc_fwd")
+            _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, w_split_layout, _p(amax_x), _p(amax_w),
+            _p(tile_stats), self._stream())), "sgg_conv2d_nhwc_fwd")
 
-    def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None):
+    def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None, w_split_layout=0):
         self._dev(dy, w_hwio, dx)
         d = self._conv_dims(dx.shape, w_hwio.shape, stride)
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        self._check(self._timed(self.gather_symbol(d[3], w_split is not None), flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
-            _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, _p(amax_dy), _p(amax_w), self._stream())),
-            "sgg_conv2d_nhwc_dgrad")
+        sym = self.halo_symbol(d[3]) if w_split_layout == 1 else self.gather_symbol(d[3], w_split is not None)
+        self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
+            _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),
+            self._stream())), "sgg_conv2d_nhwc_dgrad")
 
     def conv_wgrad(self, x, dy, dw, stride, amax_x=None, amax_dy=None):
         self._dev(x, dy, dw)

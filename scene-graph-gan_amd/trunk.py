@@ -39,15 +39,19 @@ class Trunk:
             lay["w_fwd"] = lay["w"] if cin == 3 else torch.empty((k, k, cout, cin), device=dev, dtype=dt)
             # split modes: both weight layouts pre-split into 16-bit planes once per optimiser step (HIP backend only)
             lay["ws_fwd"] = lay["ws_bwd"] = None
+            # 3x3 stride-1 layers on 8-divisible grids: halo-resident kernel, weights pre-arranged as MFMA fragments
+            # (re-derived in refresh_weights: the layout depends on the conv precision in force)
+            lay["hin"], lay["win"] = h, w
+            lay["ws_layout"] = K.conv_wsplit_layout(k, s, h, w, cin, cout) if (cin != 3 and hasattr(K, "conv_wsplit_layout")) else 0
             if cin != 3 and getattr(K, "conv_precision", 0) and hasattr(K, "split_weights"):
                 lay["ws_fwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
                 lay["ws_bwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
             lay["tstats"] = None
             if has_ln and hasattr(K, "conv_tile_stats_count"):
-                nts = K.conv_tile_stats_count((B, ho, wo, cout), cin)
+                nts = K.conv_tile_stats_count((B, ho, wo, cout), cin, k, s, lay["ws_layout"])
                 if nts > 0:     # the conv epilogue emits the LayerNorm partial statistics for this shape
                     lay["tstats"] = torch.zeros((B, nts, 3), device=dev, dtype=dt)
-                    lay["tstats_mode"] = K.conv_precision
+                    lay["tstats_mode"] = (K.conv_precision, lay["ws_layout"])
             if has_ln:
                 lay["gamma"], lay["beta"] = p[ln_name(i) + "/gamma"], p[ln_name(i) + "/beta"]
                 lay["ggamma"], lay["gbeta"] = g[ln_name(i) + "/gamma"], g[ln_name(i) + "/beta"]
@@ -81,8 +85,9 @@ class Trunk:
                 if self._f16():
                     self.K.absmax(lay["w"], self._am(2, j))
                 if lay["ws_fwd"] is not None and self.K.conv_precision:
-                    self.K.split_weights(lay["w_fwd"], lay["ws_fwd"], self._am(2, j))
-                    self.K.split_weights(lay["w"], lay["ws_bwd"], self._am(2, j))
+                    lay["ws_layout"] = self.K.conv_wsplit_layout(lay["k"], lay["s"], lay["hin"], lay["win"], lay["cin"], lay["cout"])
+                    self.K.split_weights(lay["w_fwd"], lay["ws_fwd"], self._am(2, j), lay["ws_layout"])
+                    self.K.split_weights(lay["w"], lay["ws_bwd"], self._am(2, j), lay["ws_layout"])
                     lay["ws_mode"] = self.K.conv_precision
 
     def forward(self, images):
@@ -95,9 +100,11 @@ class Trunk:
             K.fill(self.amax[0], 0.0)
         for j, lay in enumerate(self.layers):
             ws = lay["ws_fwd"] if (lay["ws_fwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
-            ts = lay["tstats"] if (lay["tstats"] is not None and lay.get("tstats_mode") == getattr(K, "conv_precision", 0)) else None
+            ts = lay["tstats"] if (lay["tstats"] is not None and ws is not None
+                                   and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])) else None
             if ws is not None or self._f16() or ts is not None:
-                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j), ts)
+                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j), ts,
+                           lay["ws_layout"] if ws is not None else 0)
             else:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             if lay["has_ln"]:
@@ -137,7 +144,7 @@ class Trunk:
             dYp = self._dY[:numel].view(prev["out_shape"])
             ws = lay["ws_bwd"] if (lay["ws_bwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
             if ws is not None or f16:
-                K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j))
+                K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout"] if ws is not None else 0)
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])
             if f16:

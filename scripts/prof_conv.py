@@ -18,8 +18,13 @@ y = torch.empty((B, Ho, Ho, Co), device="cuda")
 dy = torch.randn((B, Ho, Ho, Co), device="cuda")
 dx = torch.empty_like(x); dw = torch.empty_like(w)
 wf = torch.empty((k, k, Co, Ci), device="cuda"); K.hwio_to_hwoi(w, wf)
+lay = K.conv_wsplit_layout(k, s, H, H, Ci, Co)
+am = torch.zeros(2, device="cuda"); K.absmax(x, am[0:1]); K.absmax(w, am[1:2])
+ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+if mode == "fwd_ws": K.split_weights(wf, ws, am[1:2], lay)
 def run():
     if mode == "fwd": K.conv_fwd(x, w, wf, b, y, s)
+    elif mode == "fwd_ws": K.conv_fwd(x, w, wf, b, y, s, ws, am[0:1], am[1:2], None, lay)
     elif mode == "dgrad": K.conv_dgrad(dy, w, dx, s)
     else: K.conv_wgrad(x, dy, dw, s)
 run(); torch.cuda.synchronize()

@@ -347,6 +347,81 @@ def test_errors_are_loud(hip):
         hip.fill(torch.zeros(4), 1.0)                    # CPU tensor: no fallback
 
 
+HALO_CASES = [
+    # B, H, W, Cin, Cout  (3x3, stride 1, grids divisible by 8)
+    (2, 16, 24, 32, 32),
+    (1, 8, 8, 32, 64),          # a single 8x8 block: the other blocks of the workgroup are dead
+    (3, 8, 16, 64, 64),
+    (2, 24, 16, 64, 128),
+    (3, 8, 8, 128, 128),        # odd number of blocks
+    (1, 16, 16, 128, 256),
+    (2, 8, 8, 256, 256),
+]
+
+
+@pytest.mark.parametrize("mode", [2, 3], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
+    """Halo-resident 3x3 stride-1 kernel (weights as MFMA fragments) vs the fp64 reference and vs the gather kernel."""
+    B, H, W, Ci, Co = case
+    old = hip.conv_precision
+    hip.conv_precision = mode
+    try:
+        tol = {2: 2e-5, 3: 1e-4}[mode]
+        assert hip.conv_wsplit_layout(3, 1, H, W, Ci, Co) == 1
+        assert hip.conv_wsplit_layout(3, 1, H + 1, W, Ci, Co) == 0 and hip.conv_wsplit_layout(5, 2, H, W, Ci, Co) == 0
+        x, w, b = rnd((B, H, W, Ci), 11), rnd((3, 3, Ci, Co), 12, 1.0 / math.sqrt(9 * Ci)), rnd((Co,), 13, 0.1)
+        dy = rnd((B, H, W, Co), 14)
+        y_ref = torch.empty((B, H, W, Co), dtype=torch.float64)
+        ref.conv_fwd(x.double(), w.double(), None, b.double(), y_ref, 1)
+        dx_ref = torch.empty((B, H, W, Ci), dtype=torch.float64)
+        ref.conv_dgrad(dy.double(), w.double(), dx_ref, 1)
+        xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+        wf = torch.empty((3, 3, Co, Ci), device="cuda")
+        hip.hwio_to_hwoi(wd, wf)
+        ws_f = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+        ws_b = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+        hip.split_weights(wf, ws_f, layout=1)
+        hip.split_weights(wd, ws_b, layout=1)
+        y = torch.full((B, H, W, Co), float("nan"), device="cuda")
+        hip.conv_fwd(xd, wd, wf, bd, y, 1, ws_f, w_split_layout=1)
+        close(y, y_ref, rtol=tol, what="halo conv_fwd %s" % (case,))
+        dx = torch.full((B, H, W, Ci), float("nan"), device="cuda")
+        hip.conv_dgrad(dyd, wd, dx, 1, ws_b, w_split_layout=1)
+        close(dx, dx_ref, rtol=tol, what="halo conv_dgrad %s" % (case,))
+        # same operands through the gather kernel: identical pieces and products, only the summation order differs
+        y_g = torch.empty_like(y)
+        hip.conv_fwd(xd, wd, wf, bd, y_g, 1)
+        close(y, y_g.cpu(), rtol=5e-6, what="halo vs gather")
+        # LayerNorm partial statistics from the halo epilogue
+        nts = hip.conv_tile_stats_count((B, H, W, Co), Ci, 3, 1, 1)
+        assert nts == (H * W // 64) * (Co // (64 if Co % 64 == 0 else 32))
+        ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+        y2 = torch.empty_like(y)
+        hip.conv_fwd(xd, wd, wf, bd, y2, 1, ws_f, tile_stats=ts, w_split_layout=1)
+        assert torch.equal(y2, y)
+        gamma, beta = dev(1.0 + rnd((Co,), 15, 0.2)), dev(rnd((Co,), 16, 0.2))
+        a1, a2 = torch.empty_like(y), torch.empty_like(y)
+        st1, st2 = torch.empty((B, 2), device="cuda"), torch.empty((B, 2), device="cuda")
+        hip.ln_elu_fwd(y, gamma, beta, a1, st1, tile_stats=ts)
+        hip.ln_elu_fwd(y, gamma, beta, a2, st2)
+        close(st1, st2.cpu(), rtol=1e-6, what="stats from the halo epilogue vs statistics pass")
+        close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+    finally:
+        hip.conv_precision = old
+
+
+def test_conv_halo_rejects_bad_shapes(hip):
+    from sgg_amd.lib import SggError
+    if hip.conv_precision not in (2, 3):
+        pytest.skip("halo kernel exists for precision 2 / 3")
+    x = torch.zeros((1, 12, 12, 32), device="cuda")      # 12 % 8 != 0
+    w = torch.zeros((3, 3, 32, 32), device="cuda")
+    ws = torch.zeros((2, w.numel()), dtype=torch.int16, device="cuda")
+    with pytest.raises(SggError):
+        hip.conv_fwd(x, w, w, torch.zeros(32, device="cuda"), torch.zeros_like(x), 1, ws, w_split_layout=1)
+
+
 @pytest.mark.parametrize("cout", [32, 64, 128])
 def test_conv_epilogue_layernorm_stats(hip, ref, cout):
     """The split conv kernels can emit per-tile (count, mean, M2) of their output; LayerNorm merged from those
