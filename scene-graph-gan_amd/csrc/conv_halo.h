@@ -22,3 +22,20 @@ int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, 
 // columns covered by one (count, mean, M2) partial of the halo kernel for N output channels
 int sgg_halo_stats_cols(int N);
 void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st);
+
+// ---- halo-resident 3x3 stride-1 wgrad (conv_wgrad_halo.hip) ---------------------------------------------------
+struct WgradHaloPlan {
+  int ct, nt;           // channel chunk of a workgroup: 32*ct input x 32*nt output channels
+  int nbs;              // 8x8 blocks staged together
+  int spw;              // partial slabs a workgroup writes (waves that split the pixels of a chunk)
+  int pairs, pairs_n;   // (Cin chunk, Cout chunk) pairs; Cout chunks
+  int nsplit;           // workgroups along the pixel dimension
+  int stages;           // stages per workgroup
+  int nslabs;           // nsplit * spw
+  size_t ws_bytes;
+};
+// returns 1 and fills the plan if the shape is served (3x3, stride 1, H % 8 == W % 8 == 0, channels % 32 == 0)
+int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradHaloPlan* pl);
+// writes pl.nslabs partial dW slabs [slab][9][Cin][Cout] (unscaled f32) into `slabs`
+void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int precision,
+                           const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl, hipStream_t st);

@@ -8,6 +8,8 @@
 // the LDS tiles are in MC layout, mma_f32.h) and writes an f32 partial slab; a second kernel sums the
 // slabs in a fixed order (deterministic, no atomics).
 #include "mma_f32.h"
+#include "conv_halo.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -530,8 +532,16 @@ static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, in
 
 extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH,
                                                         int KW) {
-  (void)Hi; (void)Wi;
-  return wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW).ws_bytes;
+  size_t need = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW).ws_bytes;
+  WgradHaloPlan hp;     // (precision and stride are not known here: upper bound over both kernels)
+  if (Hi == Ho && Wi == Wo && sgg_wgrad_halo_plan(B, Hi, Wi, Cin, Cout, KH, KW, 1, &hp) && hp.ws_bytes > need) need = hp.ws_bytes;
+  return need;
+}
+
+// SGG_CONV_HALO=0 keeps the 3x3 stride-1 layers on the per-tap kernels (A/B measurements)
+static bool wgrad_halo_enabled() {
+  static const bool on = [] { const char* e = getenv("SGG_CONV_HALO"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,
@@ -554,6 +564,21 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
     }
   }
   const long long nout = (long long)KH * KW * Cin * Cout;
+  WgradHaloPlan hp;
+  if ((precision == 2 || precision == 3) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho && Wi == Wo && wgrad_halo_enabled() &&
+      sgg_wgrad_halo_plan(B, Hi, Wi, Cin, Cout, KH, KW, stride, &hp)) {
+    // halo-resident kernel: the nine taps of a channel chunk from one LDS-resident patch (conv_wgrad_halo.hip)
+    if (!workspace || workspace_bytes < hp.ws_bytes) {
+      sgg_set_error("sgg_conv2d_nhwc_wgrad: workspace too small (%zu < %zu)", workspace_bytes, hp.ws_bytes);
+      return SGG_ERR_WORKSPACE;
+    }
+    sgg_wgrad_halo_launch(x, dy, (float*)workspace, B, Hi, Wi, Cin, Cout, precision, amax_x, amax_dy, hp, st);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo)");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sgg_cdiv(nout / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                       nout / 4, hp.nslabs);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo reduce)");
+    return SGG_OK;
+  }
   if (Cin == 3) {
     SGG_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && Cout == 32, "sgg_conv2d_nhwc_wgrad: Cin=3 path needs 3x3 s1 Cout=32");
     hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, B, Hi, Wi, pad_t,

@@ -1,0 +1,272 @@
+// Halo-resident Conv2DBackpropFilter for the 3x3 / stride-1 layers in the split 16-bit modes (gfx950):
+//   dW[kh][kw][ci][co] = sum_{b,y,x} x[b, y+kh-1, x+kw-1, ci] * dy[b, y, x, co]
+// Reference: autodiff of tf.layers.conv2d(kernel_size=3, padding="same") (architectures/generator_with_attention.py:31-57)
+// under optimizer.minimize (train.py:265-266).
+//
+// The per-tap GEMM kernels (conv_wgrad.hip) re-read x and dy for each of the nine taps and, for the 32/64-channel
+// layers, run one 32x32 MFMA tile per workgroup and tap (8 FLOP per byte fetched).  Here a workgroup owns a
+// (32*CT input) x (32*NT output) channel chunk and a contiguous range of 8x8 pixel blocks; per stage the 10x10 input
+// patch (halo included) and the 8x8 dy block are split into two 16-bit planes and written to LDS ONCE, and every wave
+// contracts its 32x32 channel tile for all nine taps out of the resident patch: 9 accumulator tiles per wave
+// (144 VGPRs), contraction over the block's 64 pixels (four 16-pixel MFMA steps).  Both MFMA operands need 8
+// consecutive PIXELS of one channel per lane; they are fetched from the [pixel][channel] planes with the gfx950
+// transposing LDS read ds_read_b64_tr_b16, each lane addressing its own pixel, so that a tap shift is an immediate
+// offset on one base register (no per-tap address arithmetic at all).  Rows are 64 B (32 channels) and a 32-lane
+// phase of the read covers 4 consecutive pixel slots = 256 contiguous bytes: conflict free without a swizzle.
+// Partial sums go to f32 slabs [slab][9][Cin][Cout] summed in fixed order by slab_reduce_kernel (deterministic).
+#include "split16.h"
+#include "conv_halo.h"
+
+typedef short s16x4h __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x2h lds_tr16(const unsigned char* p) {
+  return __builtin_bit_cast(u32x2h, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4h*)p));
+}
+
+struct WgradHaloParams {
+  const float* x;
+  const float* dy;
+  float* slabs;
+  const float* amax_x;
+  const float* amax_dy;
+  int H, W, C, N;         // C = Cin, N = Cout
+  int bh, bw, nblk;       // 8x8 blocks per image (rows, cols) and in total
+  int pairs_n;            // Cout chunks
+  int stages;             // stages per workgroup (NBS blocks each)
+  unsigned x_bytes, dy_bytes;
+};
+
+template <int CT, int NT, bool HALF, bool PREF>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParams p) {
+  constexpr int P = 2;
+  constexpr int NBS = (CT == 2) ? 1 : 2;                 // blocks per stage
+  constexpr int KSW = (CT == 1 && NT == 1) ? 2 : 4;      // 16-pixel MFMA steps per wave and block
+  constexpr int SPW = 4 / (CT * NT) ;                    // waves that share a channel tile (own slabs)
+  constexpr int XSUB = 120 * 64;                         // bytes of one 32-channel sub-plane of a block's patch (10 x pitch 12)
+  constexpr int XPLANE = NBS * CT * XSUB;
+  constexpr int DSUB = 64 * 64;
+  constexpr int DPLANE = NBS * NT * DSUB;
+  constexpr int XI = 400 * CT, XP = (XI + 255) / 256;    // x staging items (patch pixel, 8 channels) per block, passes
+  constexpr int DI = 256 * NT, DP = DI / 256;
+  constexpr int NPASS = NBS * (XP + DP);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[P * (XPLANE + DPLANE)];
+  unsigned char* x_s = lds;
+  unsigned char* d_s = lds + P * XPLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x, pair = blockIdx.y;
+  const int c0 = (pair / p.pairs_n) * 32 * CT, n0 = (pair % p.pairs_n) * 32 * NT;
+  // wave roles
+  int ci_t, co_t, wblk, ks0, sw;
+  if constexpr (CT == 2) { ci_t = wave >> 1; co_t = wave & 1; wblk = 0; ks0 = 0; sw = 0; }
+  else if constexpr (NT == 2) { ci_t = 0; co_t = wave & 1; wblk = wave >> 1; ks0 = 0; sw = wave >> 1; }
+  else { ci_t = 0; co_t = 0; wblk = wave >> 1; ks0 = 2 * (wave & 1); sw = wave; }
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  int ea = 0, eb = 0;
+  if constexpr (HALF) {
+    ea = scale_exp_from_amax(*p.amax_x);
+    eb = scale_exp_from_amax(*p.amax_dy);
+  }
+  const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
+
+  // ---- staging plan: pass -> (kind, block); item -> offset relative to the block origin, border bits, LDS offset ----
+  unsigned it_rel[NPASS];
+  int it_lds[NPASS];        // bits 0..19 LDS byte offset inside a plane, bits 20..23 border bits, bit 24 valid
+#pragma unroll
+  for (int j = 0; j < NPASS; ++j) {
+    const int blk = j / (XP + DP), jj = j % (XP + DP);
+    if (jj < XP) {
+      const int i = tid + 256 * jj;
+      const int csub = i / 400, r = i % 400;
+      const int px = r >> 2, c4 = r & 3;
+      const int ry = px / 10, rx = px % 10;
+      it_rel[j] = (unsigned)(((ry * p.W + rx) * p.C + csub * 32 + c4 * 8) * 4);
+      const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
+      it_lds[j] = ((blk * CT + csub) * XSUB + (ry * 12 + rx) * 64 + c4 * 16) | (bits << 20) | ((i < XI) << 24);
+    } else {
+      const int i = tid + 256 * (jj - XP);
+      const int nsub = i >> 8, r = i & 255;
+      const int px = r >> 2, c4 = r & 3;
+      it_rel[j] = (unsigned)((((px >> 3) * p.W + (px & 7)) * p.N + nsub * 32 + c4 * 8) * 4);
+      it_lds[j] = ((blk * NT + nsub) * DSUB + px * 64 + c4 * 16) | (1 << 24);
+    }
+  }
+
+  // block coordinates of the NBS staged blocks, advanced by NBS per stage
+  const int bpi = p.bh * p.bw;
+  const int blk_begin = split * p.stages * NBS;
+  int cb[NBS], cy[NBS], cx[NBS];
+#pragma unroll
+  for (int j = 0; j < NBS; ++j) {
+    const int beta = blk_begin + j;
+    cb[j] = beta / bpi;
+    const int rem = beta % bpi;
+    cy[j] = rem / p.bw;
+    cx[j] = rem % p.bw;
+  }
+  int next_beta = blk_begin;       // first block of the stage the next stage_load fetches
+
+  f32x4 pre[NPASS][2];
+  auto stage_load = [&]() {
+#pragma unroll
+    for (int blk = 0; blk < NBS; ++blk) {
+      const bool dead = (next_beta + blk >= p.nblk) | (next_beta + blk >= blk_begin + p.stages * NBS);
+      const int by = cy[blk], bx = cx[blk];
+      const unsigned xbase = (unsigned)((((cb[blk] * p.H + by * 8 - 1) * p.W + bx * 8 - 1) * p.C + c0) * 4);
+      const unsigned dbase = (unsigned)((((cb[blk] * p.H + by * 8) * p.W + bx * 8) * p.N + n0) * 4);
+      const int bbits = (by == 0) | ((by == p.bh - 1) << 1) | ((bx == 0) << 2) | ((bx == p.bw - 1) << 3);
+#pragma unroll
+      for (int jj = 0; jj < XP + DP; ++jj) {
+        const int j = blk * (XP + DP) + jj;
+        const bool isx = jj < XP;
+        const bool bad = dead | !((it_lds[j] >> 24) & 1) | (isx && (((it_lds[j] >> 20) & 15 & bbits) != 0));
+        const unsigned off = bad ? SGG_OOB : (isx ? xbase : dbase) + it_rel[j];
+        if (isx) {
+          pre[j][0] = buf_load4(rs_x, off);
+          pre[j][1] = buf_load4(rs_x, off + 16u);
+        } else {
+          pre[j][0] = buf_load4(rs_dy, off);
+          pre[j][1] = buf_load4(rs_dy, off + 16u);
+        }
+      }
+      // advance this slot to the next stage's block
+      cx[blk] += NBS;
+      while (cx[blk] >= p.bw) {
+        cx[blk] -= p.bw;
+        if (++cy[blk] >= p.bh) { cy[blk] = 0; ++cb[blk]; }
+      }
+    }
+    next_beta += NBS;
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+      const bool isx = (j % (XP + DP)) < XP;
+      u32x4 pl[P];
+      split8<P, HALF>(pre[j][0], pre[j][1], isx ? sa : sb, pl);
+      if ((it_lds[j] >> 24) & 1) {
+        unsigned char* dst = (isx ? x_s : d_s) + (it_lds[j] & 0xfffff);
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * (isx ? XPLANE : DPLANE)) = pl[pp];
+      }
+    }
+  };
+
+  // transposing-read lane roles (see conv_wgrad_tr_kernel): 16-lane group g -> k half (g >> 1), channel half (g & 1);
+  // lane 4q+pch of the group addresses pixel q (lo) / q+4 (hi) of the k half's row and channels 4pch..4pch+3
+  const int g = lane >> 4, q = (lane >> 2) & 3, pch = lane & 3;
+  const int choff = ((g & 1) * 2 + (pch >> 1)) * 16 + (pch & 1) * 8;
+  const unsigned char* a_base = x_s + (wblk * CT + ci_t) * XSUB + ((2 * ks0 + (g >> 1)) * 12 + q) * 64 + choff;
+  const unsigned char* b_base = d_s + (wblk * NT + co_t) * DSUB + ((2 * ks0 + (g >> 1)) * 8 + q) * 64 + choff;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int ksi = 0; ksi < KSW; ++ksi) {
+      u32x4 b[P];
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) {
+        const u32x2h lo = lds_tr16(b_base + (2 * ksi * 8) * 64 + pp * DPLANE);
+        const u32x2h hi = lds_tr16(b_base + (2 * ksi * 8 + 4) * 64 + pp * DPLANE);
+        b[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        u32x4 a[P];
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+          const u32x2h lo = lds_tr16(a_base + ((2 * ksi + kh) * 12 + kw) * 64 + pp * XPLANE);
+          const u32x2h hi = lds_tr16(a_base + ((2 * ksi + kh) * 12 + kw + 4) * 64 + pp * XPLANE);
+          a[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        f32x16 d = acc[tap];
+        d = mfma16<HALF>(a[1], b[0], d);
+        d = mfma16<HALF>(a[0], b[1], d);
+        d = mfma16<HALF>(a[0], b[0], d);
+        acc[tap] = d;
+      }
+    }
+  };
+
+  stage_load();
+  stage_write();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < p.stages; ++s) {
+    if constexpr (PREF) stage_load();        // next stage's blocks (out-of-range offsets past the end: zeros, no traffic)
+    __builtin_amdgcn_sched_barrier(0);
+    compute();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (!PREF) stage_load();
+    stage_write();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- partial slab: [slab][tap][Cin][Cout] -------------------------------------------------------------------
+  float* o = p.slabs + (size_t)(split * SPW + sw) * 9 * p.C * p.N;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = c0 + ci_t * 32 + acc_row(r, lane);
+      const int co = n0 + co_t * 32 + acc_col(lane);
+      const float v = acc[tap][r];
+      o[((size_t)tap * p.C + ci) * p.N + co] = HALF ? ldexpf(ldexpf(v, -ea), -eb) : v;
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------
+int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradHaloPlan* pl) {
+  if (!(KH == 3 && KW == 3 && stride == 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cin % 32 == 0 && Cout % 32 == 0 && B > 0))
+    return 0;
+  if ((size_t)B * H * W * Cin * sizeof(float) >= 0x80000000ull || (size_t)B * H * W * Cout * sizeof(float) >= 0x80000000ull) return 0;
+  if (Cin % 64 == 0 && Cout % 64 == 0) { pl->ct = 2; pl->nt = 2; }
+  else if (Cout % 64 == 0) { pl->ct = 1; pl->nt = 2; }
+  else { pl->ct = 1; pl->nt = 1; }
+  pl->nbs = pl->ct == 2 ? 1 : 2;
+  pl->spw = 4 / (pl->ct * pl->nt);
+  pl->pairs_n = Cout / (32 * pl->nt);
+  pl->pairs = (Cin / (32 * pl->ct)) * pl->pairs_n;
+  const int nblk = B * (H / 8) * (W / 8);
+  const int total_stages = (nblk + pl->nbs - 1) / pl->nbs;
+  int ns = 512 / pl->pairs;                       // one resident round of 2 workgroups per CU
+  if (ns > total_stages / 8) ns = total_stages / 8;
+  if (ns < 1) ns = 1;
+  pl->stages = (total_stages + ns - 1) / ns;
+  pl->nsplit = (total_stages + pl->stages - 1) / pl->stages;
+  pl->nslabs = pl->nsplit * pl->spw;
+  pl->ws_bytes = (size_t)pl->nslabs * 9 * Cin * Cout * sizeof(float);
+  return 1;
+}
+
+void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int precision,
+                           const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl, hipStream_t st) {
+  WgradHaloParams p;
+  p.x = x; p.dy = dy; p.slabs = slabs; p.amax_x = amax_x; p.amax_dy = amax_dy;
+  p.H = H; p.W = W; p.C = Cin; p.N = Cout; p.bh = H / 8; p.bw = W / 8; p.nblk = B * p.bh * p.bw;
+  p.pairs_n = pl.pairs_n; p.stages = pl.stages;
+  p.x_bytes = (unsigned)((size_t)B * H * W * Cin * sizeof(float));
+  p.dy_bytes = (unsigned)((size_t)B * H * W * Cout * sizeof(float));
+  const dim3 grid(pl.nsplit, pl.pairs);
+  const bool half = precision == 2;
+#define SGG_WH(CT, NT, PF)                                                                                        \
+  do {                                                                                                            \
+    if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF>), grid, dim3(256), 0, st, p);           \
+    else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF>), grid, dim3(256), 0, st, p);               \
+  } while (0)
+  if (pl.ct == 2) SGG_WH(2, 2, true);
+  else if (pl.nt == 2) SGG_WH(1, 2, false);
+  else SGG_WH(1, 1, true);
+#undef SGG_WH
+}

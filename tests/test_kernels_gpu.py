@@ -356,6 +356,8 @@ HALO_CASES = [
     (3, 8, 8, 128, 128),        # odd number of blocks
     (1, 16, 16, 128, 256),
     (2, 8, 8, 256, 256),
+    (5, 40, 24, 32, 32),        # 75 blocks: several stages per workgroup, ragged last stage
+    (3, 24, 40, 64, 64),
 ]
 
 
@@ -389,6 +391,12 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
         dx = torch.full((B, H, W, Ci), float("nan"), device="cuda")
         hip.conv_dgrad(dyd, wd, dx, 1, ws_b, w_split_layout=1)
         close(dx, dx_ref, rtol=tol, what="halo conv_dgrad %s" % (case,))
+        # Conv2DBackpropFilter: the entry point routes 3x3 stride-1 shapes on 8-divisible grids to the halo-resident kernel
+        dw_ref = torch.empty((3, 3, Ci, Co), dtype=torch.float64)
+        ref.conv_wgrad(x.double(), dy.double(), dw_ref, 1)
+        dw = torch.full((3, 3, Ci, Co), float("nan"), device="cuda")
+        hip.conv_wgrad(xd, dyd, dw, 1)
+        close(dw, dw_ref, rtol=tol, what="halo conv_wgrad %s" % (case,))
         # same operands through the gather kernel: identical pieces and products, only the summation order differs
         y_g = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y_g, 1)
