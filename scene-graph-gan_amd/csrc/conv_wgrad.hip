@@ -432,12 +432,48 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_tr_kernel(WgradParams p) {
 }
 
 // out[e] = sum_s slabs[s][e]   (fixed order -> deterministic)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4, int nsplit) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
-  for (int k = 1; k < nsplit; ++k) s += reinterpret_cast<const f32x4*>(slabs)[(long long)k * n4 + i];
-  reinterpret_cast<f32x4*>(out)[i] = s;
+// A workgroup owns EPB float4 elements and splits the slabs over SG = 256 / EPB thread groups (group g sums slabs
+// g, g + SG, ...), combined through LDS in group order: small dW tensors (conv1_2: 2304 float4 x 2048 slabs) would
+// otherwise run on 9 workgroups with 2048 serial loads per thread.
+template <int EPB>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4,
+                                                          int nsplit) {
+  constexpr int SG = 256 / EPB;
+  __shared__ f32x4 red[256];
+  const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
+  const long long i = (long long)blockIdx.x * EPB + e;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + i;
+    int k = g;
+    for (; k + 3 * SG < nsplit; k += 4 * SG) {      // four independent loads in flight
+      const f32x4 v0 = src[(long long)k * n4], v1 = src[(long long)(k + SG) * n4];
+      const f32x4 v2 = src[(long long)(k + 2 * SG) * n4], v3 = src[(long long)(k + 3 * SG) * n4];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < nsplit; k += SG) s += src[(long long)k * n4];
+  }
+  if constexpr (SG > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+#pragma unroll
+      for (int j = 1; j < SG; ++j) s += red[j * EPB + e];
+      reinterpret_cast<f32x4*>(out)[i] = s;
+    }
+  } else {
+    if (i < n4) reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+
+static void launch_slab_reduce(const float* slabs, float* out, long long n4, int nsplit, hipStream_t st) {
+  // enough workgroups to fill the chip, and every thread group still sums several slabs
+  if (n4 >= 256 * 1024 || nsplit < 8)
+    hipLaunchKernelGGL(slab_reduce_kernel<256>, dim3(sgg_cdiv(n4, 256)), dim3(256), 0, st, slabs, out, n4, nsplit);
+  else if (n4 >= 32 * 1024 || nsplit < 64)
+    hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3(sgg_cdiv(n4, 64)), dim3(256), 0, st, slabs, out, n4, nsplit);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(sgg_cdiv(n4, 16)), dim3(256), 0, st, slabs, out, n4, nsplit);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -574,8 +610,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
     }
     sgg_wgrad_halo_launch(x, dy, (float*)workspace, B, Hi, Wi, Cin, Cout, precision, amax_x, amax_dy, hp, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo)");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sgg_cdiv(nout / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                       nout / 4, hp.nslabs);
+    launch_slab_reduce((const float*)workspace, dw, nout / 4, hp.nslabs, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo reduce)");
     return SGG_OK;
   }
@@ -584,8 +619,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
     hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, B, Hi, Wi, pad_t,
                        pad_l, pl.chunk);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3)");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sgg_cdiv(nout / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                       nout / 4, pl.nsplit);
+    launch_slab_reduce((const float*)workspace, dw, nout / 4, pl.nsplit, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3 reduce)");
     return SGG_OK;
   }
@@ -630,8 +664,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
 #undef SGG_WG
   SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad");
   if (pl.nsplit > 1) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sgg_cdiv(nout / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                       nout / 4, pl.nsplit);
+    launch_slab_reduce((const float*)workspace, dw, nout / 4, pl.nsplit, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(reduce)");
   }
   return SGG_OK;
