@@ -15,6 +15,7 @@ struct HaloParams {
   int bh, bw, nblk;       // 8x8 blocks per image (rows, cols) and in total
   int flip;               // 0: forward (correlation); 1: dgrad (taps mirrored)
   unsigned src_bytes, w_bytes;
+  int gx;                 // workgroups per XCD (set by sgg_halo_launch)
 };
 
 // 1 if the halo kernel serves a 3x3 / stride-1 convolution over an H x W grid in this precision

@@ -24,30 +24,37 @@
 
 __device__ __forceinline__ int halo_sw(int ry, int rx) { return ((rx >> 2) & 1) | ((ry & 1) << 1); }
 
-template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH>
+// ONECH: C == 32 (one chunk per tile); otherwise C % 64 == 0 (an even number of chunks): the B-fragment double buffer
+// flips once per chunk (nine taps), so chunks are unrolled in pairs - a run-time parity branch between two chunk bodies
+// costs ~110 spilled VGPRs at the merge.
+template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH>
 __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   constexpr int P = 2;
-  constexpr int BM = NB * 64, WN = BN / WGN, TM = 2, TN = WN / 32;
-  static_assert(WGM * WGN == 4 && BM / WGM == 64 && WN % 32 == 0 && TN >= 1, "a wave owns one 8x8 block x WN columns");
+  constexpr int WN = BN / WGN, TM = 2, TN = WN / 32;
+  static_assert(WGM * WGN == 4 && NB * 64 / WGM == 64 && WN % 32 == 0 && TN >= 1, "a wave owns one 8x8 block x WN columns");
   constexpr int PLANEB = NB * HALO_BLKB;
   constexpr int ITEMS = NB * 400;                       // (block, patch pixel, 8-channel group)
   constexpr int NPASS = (ITEMS + 255) / 256;
-  // (PREFETCH: the staging offsets live in LDS - in registers they are spilled, and a scratch reload in the tap loop
-  //  waits for every load in flight)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[P * PLANEB + BM * 4 + (PREFETCH ? NPASS * 1024 : 0)];
-  int* out_off_s = reinterpret_cast<int*>(lds + P * PLANEB);
-  unsigned* it_off_s = reinterpret_cast<unsigned*>(lds + P * PLANEB + BM * 4);
+  constexpr bool DB = (2 * P * PLANEB <= 65536);        // two patch buffers: one barrier per chunk instead of two
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(DB ? 2 : 1) * P * PLANEB];
 
+  // ---- persistent workgroup ----------------------------------------------------------------------------------------
+  // XCD k (workgroup ids are dealt round-robin to the 8 XCDs) owns a contiguous eighth of the M-tiles (NB blocks each);
+  // its p.gx workgroups walk that range interleaved (tile = first + j + i * stride), so the workgroups resident on an XCD
+  // always work on a contiguous window of tiles: halo rows and the patch shared by the n-tiles of one pixel range hit
+  // in that XCD's L2.
   const int ntiles_n = p.N / BN;
   const int mtiles = (p.nblk + NB - 1) / NB;
-  const int nwg = mtiles * ntiles_n;
-  if ((int)blockIdx.x >= nwg) return;
-  const int lid = xcd_remap(blockIdx.x, nwg);
-  const int mt = lid / ntiles_n, nt = lid % ntiles_n;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nt = jx % ntiles_n;
+  const int tstride = p.gx / ntiles_n;
+  const int mt_begin = (int)(((long long)xcd * mtiles) >> 3) + jx / ntiles_n;
+  const int mt_end = (int)(((long long)(xcd + 1) * mtiles) >> 3);
+  if (mt_begin >= mt_end) return;
   const int n0 = nt * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wblk = wave / WGN, wn0 = (wave % WGN) * WN;
-  const int bpi = p.bh * p.bw;
 
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
@@ -58,64 +65,92 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   }
   const float sa = ldexpf(1.f, ea);
 
-  // ---- staging plan: item -> (global byte offset of 8 channels of a patch pixel, LDS byte offset inside a plane) ----
-  unsigned it_off[NPASS];
-  int it_lds[NPASS];
+  // ---- staging plan (static per thread): item -> offset relative to its block's patch origin, border bits, LDS offset ----
+  unsigned it_rel[NPASS];
+  int it_meta[NPASS];      // bits 0..19 LDS byte offset inside a plane, 20..23 border bits, 24..25 block, 28 valid
 #pragma unroll
   for (int j = 0; j < NPASS; ++j) {
     const int it = tid + 256 * j;
     const int blk = it / 400, r = it % 400;
     const int px = r >> 2, ch8 = r & 3;
     const int ry = px / 10, rx = px % 10;
-    const int beta = mt * NB + blk;
-    const bool valid = it < ITEMS;
-    unsigned off = SGG_OOB;
-    if (valid && beta < p.nblk) {
-      const int b = beta / bpi, rem = beta % bpi;
-      const int by = rem / p.bw, bx = rem % p.bw;
-      const int yy = by * 8 - 1 + ry, xx = bx * 8 - 1 + rx;
-      if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-        off = (unsigned)(((b * p.H + yy) * p.W + xx) * p.C + ch8 * 8) * 4u;
-    }
-    it_off[j] = off;
-    if constexpr (PREFETCH) it_off_s[j * 256 + tid] = off;
-    it_lds[j] = valid ? blk * HALO_BLKB + (ry * HALO_PITCH + rx) * 64 + ((ch8 ^ halo_sw(ry, rx)) << 4) : -1;
-  }
-  for (int r = tid; r < BM; r += 256) {
-    const int beta = mt * NB + (r >> 6), ml = r & 63;
-    int off = -1;
-    if (beta < p.nblk) {
-      const int b = beta / bpi, rem = beta % bpi;
-      const int by = rem / p.bw, bx = rem % p.bw;
-      off = ((b * p.H + by * 8 + (ml >> 3)) * p.W + bx * 8 + (ml & 7)) * p.N;
-    }
-    out_off_s[r] = off;
+    it_rel[j] = (unsigned)(((ry * p.W + rx) * p.C + ch8 * 8) * 4);
+    const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
+    it_meta[j] = (blk * HALO_BLKB + (ry * HALO_PITCH + rx) * 64 + ((ch8 ^ halo_sw(ry, rx)) << 4)) | (bits << 20) | ((blk & 3) << 24) |
+                 ((it < ITEMS) << 28);
   }
 
+  // block coordinates of the tile being STAGED (uniform: scalar registers): global block row (b*bh + by), by, bx
+  int s_grow[NB], s_by[NB], s_bx[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int beta = mt_begin * NB + j;
+    s_grow[j] = beta / p.bw;
+    s_bx[j] = beta % p.bw;
+    s_by[j] = s_grow[j] % p.bh;
+  }
+  int s_tile = mt_begin, s_cc = 0;
+  const int nch = p.C >> 5;
+  const int adv_rows = (tstride * NB) / p.bw, adv_cols = (tstride * NB) % p.bw;   // block advance between this workgroup's tiles
+
   f32x4 pre[NPASS][2];
-  auto stage_load = [&](int cc, bool dead) {
+  // issue the global loads of the next (tile, chunk) patch in flat order; past the last tile: out-of-range offsets (zeros)
+  auto stage_load = [&]() {
+    unsigned base[NB];
+    int bbits[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool dead = (s_tile >= mt_end) | (s_tile * NB + j >= p.nblk);
+      base[j] = (unsigned)((((s_grow[j] * 8 - 1) * p.W + s_bx[j] * 8 - 1) * p.C + s_cc * 32) * 4);
+      bbits[j] = dead ? 15 : ((s_by[j] == 0) | ((s_by[j] == p.bh - 1) << 1) | ((s_bx[j] == 0) << 2) | ((s_bx[j] == p.bw - 1) << 3));
+      // a dead block: every item masked (bits 0 -> use the valid flag below)
+      if (dead) base[j] = SGG_OOB;
+    }
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
-      const unsigned o0 = (PREFETCH && cc > 0) ? it_off_s[j * 256 + tid] : it_off[j];
-      const unsigned off = (o0 + (unsigned)cc * 128u) | (dead ? SGG_OOB : 0u);   // (the marker stays out of range)
+      const int blk = (it_meta[j] >> 24) & 3;
+      unsigned b0 = base[0];
+      int bb = bbits[0];
+#pragma unroll
+      for (int k = 1; k < NB; ++k) {
+        b0 = blk == k ? base[k] : b0;
+        bb = blk == k ? bbits[k] : bb;
+      }
+      const bool bad = !((it_meta[j] >> 28) & 1) | ((((it_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
+      const unsigned off = bad ? SGG_OOB : b0 + it_rel[j];
       pre[j][0] = buf_load4(rs_src, off);
       pre[j][1] = buf_load4(rs_src, off + 16u);
     }
+    if (++s_cc == nch) {        // advance to this workgroup's next tile
+      s_cc = 0;
+      s_tile += tstride;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        s_bx[j] += adv_cols;
+        s_grow[j] += adv_rows;
+        s_by[j] += adv_rows;
+        if (s_bx[j] >= p.bw) {
+          s_bx[j] -= p.bw;
+          ++s_grow[j];
+          ++s_by[j];
+        }
+        while (s_by[j] >= p.bh) s_by[j] -= p.bh;
+      }
+    }
   };
-  auto stage_write = [&]() {
+  auto stage_write = [&](unsigned char* dst) {
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
       u32x4 pl[P];
       split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
-      if (it_lds[j] >= 0) {
+      if ((it_meta[j] >> 28) & 1) {
 #pragma unroll
-        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(lds + pp * PLANEB + it_lds[j]) = pl[pp];
+        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PLANEB + (it_meta[j] & 0xfffff)) = pl[pp];
       }
     }
   };
 
   // ---- weights: B fragments straight from L2, layout [tap][chunk][n-tile of 32][k-step][plane][lane] x 16 B --------
-  const int nch = p.C >> 5;
   const unsigned w_lane = (unsigned)((n0 + wn0) >> 5) * 4096u + (unsigned)lane * 16u;
   const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
   u32x4 rb[2][TN][2][P];
@@ -136,24 +171,23 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
 
   const int i = lane & 31, h = lane >> 5;
   const int pyl = i >> 3, pxl = i & 7;
-  const unsigned char* patch_w = lds + wblk * HALO_BLKB;
+  int cur = 0;                  // patch buffer the current chunk reads (DB)
 
   // One 32-channel chunk = nine taps, statically unrolled and branch free, so that the compiler's s_waitcnt counts are
   // exact: every tap issues the next tap's eight B-fragment loads and waits only for its own (issued one tap earlier).
   // (With the loads under a uniform branch the counter analysis had to assume the fewest loads in flight and every tap
-  // waited for the loads it had just issued: the whole L2 latency exposed per tap.)  Past the end the B prefetch
-  // re-reads a valid fragment and the patch prefetch uses out-of-range offsets (zeros, no memory traffic).
-  // The A fragments of tap t+1 are read from LDS between the two k-steps of tap t (software pipelining inside the wave:
-  // with two waves per SIMD the other wave alone does not cover the LDS latency).
-  u32x4 a[2][TM][2][P];
-  auto read_a = [&](auto buf_c, int tap) {
-    constexpr int buf = decltype(buf_c)::value;
+  // waited for the loads it had just issued: the whole L2 latency exposed per tap.)
+  // (Reading the A fragments of tap t+1 between the two k-steps of tap t - software pipelining inside the wave - was
+  //  measured: no gain, 32 more VGPRs.)
+  u32x4 a[TM][2][P];
+  auto read_a = [&](int tap) {
     const int kh = tap / 3, kw = tap % 3;
     const int dyy = p.flip ? 2 - kh : kh, dxx = p.flip ? 2 - kw : kw;
     // (opaque to the optimiser: otherwise the 36 per-tap LDS addresses are hoisted out of the chunk loop and spilled,
     //  and each scratch reload drags a vmcnt wait for the B prefetch in flight)
     int pyv = pyl, pxv = pxl;
     asm volatile("" : "+v"(pyv), "+v"(pxv));
+    const unsigned char* patch_w = lds + (DB ? cur * (P * PLANEB) : 0) + wblk * HALO_BLKB;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int ry = tm * 4 + pyv + dyy, rx = pxv + dxx;
@@ -163,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
-          a[buf][tm][ks][pp] = *reinterpret_cast<const u32x4*>(row + pp * PLANEB + (((2 * ks + h) ^ hs) << 4));
+          a[tm][ks][pp] = *reinterpret_cast<const u32x4*>(row + pp * PLANEB + (((2 * ks + h) ^ hs) << 4));
     }
   };
   auto mma_kstep = [&](auto par_c, auto ks_c) {
@@ -173,95 +207,128 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         f32x16 d = acc[tm][tn];
-        d = mfma16<HALF>(a[par][tm][ks][1], rb[par][tn][ks][0], d);
-        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][1], d);
-        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][0], d);
+        d = mfma16<HALF>(a[tm][ks][1], rb[par][tn][ks][0], d);
+        d = mfma16<HALF>(a[tm][ks][0], rb[par][tn][ks][1], d);
+        d = mfma16<HALF>(a[tm][ks][0], rb[par][tn][ks][0], d);
         acc[tm][tn] = d;
       }
   };
-  auto tap_body = [&](auto par_c, auto tap_c, int cc, bool more) {
+  auto tap_body = [&](auto par_c, auto tap_c, int cc) {
     constexpr int par = decltype(par_c)::value, tap = decltype(tap_c)::value;
-    const int ntap = tap == 8 ? (more ? 0 : 8) : tap + 1;
-    const int ncc = tap == 8 ? (more ? cc + 1 : cc) : cc;
-    load_b(std::integral_constant<int, par ^ 1>{}, ncc, ntap);
-    if constexpr (PREFETCH && tap == 6) stage_load(cc + 1, !more);
+    const int ncc = (cc + 1 == nch) ? 0 : cc + 1;         // (the chunk after the last one re-reads valid weights)
+    load_b(std::integral_constant<int, par ^ 1>{}, tap == 8 ? ncc : cc, tap == 8 ? 0 : tap + 1);
+    if constexpr (PREFETCH && tap == 6) stage_load();
     __builtin_amdgcn_sched_barrier(0);
+    read_a(tap);
     mma_kstep(par_c, std::integral_constant<int, 0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (tap < 8) read_a(std::integral_constant<int, par ^ 1>{}, tap + 1);
-    __builtin_amdgcn_sched_barrier(0);
     mma_kstep(par_c, std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
   };
   auto chunk = [&](auto par0_c, int cc) {
     constexpr int par0 = decltype(par0_c)::value;
-    const bool more = cc + 1 < nch;
-    read_a(par0_c, 0);
-#define SGG_TAP(T) tap_body(std::integral_constant<int, (par0 + T) & 1>{}, std::integral_constant<int, T>{}, cc, more)
+#define SGG_TAP(T) tap_body(std::integral_constant<int, (par0 + T) & 1>{}, std::integral_constant<int, T>{}, cc)
     SGG_TAP(0); SGG_TAP(1); SGG_TAP(2); SGG_TAP(3); SGG_TAP(4); SGG_TAP(5); SGG_TAP(6); SGG_TAP(7); SGG_TAP(8);
 #undef SGG_TAP
-    // next chunk: replace the resident patch (zeros after the last chunk; nobody reads them)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if constexpr (!PREFETCH) stage_load(cc + 1, !more);
-    stage_write();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // next chunk (of this tile or the first of the next tile): replace the resident patch
+    if constexpr (DB) {
+      stage_write(lds + (cur ^ 1) * (P * PLANEB));        // nobody reads the other buffer since the previous barrier
+      cur ^= 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if constexpr (!PREFETCH) stage_load();
+      stage_write(lds);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   };
 
-  stage_load(0, false);
+  // this wave's output block: global block row and column, advanced by NB per tile
+  int o_grow, o_bx;
+  {
+    const int beta = mt_begin * NB + wblk;
+    o_grow = beta / p.bw;
+    o_bx = beta % p.bw;
+  }
+  const int o_lane = (4 * h * p.N) + n0 + wn0 + (lane & 31);
+  const int wn = p.W * p.N;
+
+  stage_load();
   load_b(std::integral_constant<int, 0>{}, 0, 0);
-  stage_write();
+  stage_write(lds);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  int cc = 0;
-  for (; cc + 1 < nch; cc += 2) {
-    chunk(std::integral_constant<int, 0>{}, cc);
-    chunk(std::integral_constant<int, 1>{}, cc + 1);
-  }
-  if (cc < nch) chunk(std::integral_constant<int, 0>{}, cc);
-
-  // ---- epilogue: unscale, + bias, store; optionally this wave's LayerNorm partial statistics --------------------
-  float lsum = 0.f;
+  auto epilogue = [&](int tile) {
+    // ---- tile epilogue: unscale, + bias, store; optionally this wave's LayerNorm partial statistics; clear ----------
+    const int beta = tile * NB + wblk;
+    const bool live = beta < p.nblk;
+    float* ob = p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.N + o_lane;
+    float lsum = 0.f;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + wn0 + tn * 32 + acc_col(lane);
-    const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int tn = 0; tn < TN; ++tn) {
+      const float bv = p.bias ? p.bias[n0 + wn0 + tn * 32 + acc_col(lane)] : 0.f;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wblk * 64 + tm * 32 + acc_row(r, lane);
-        const int off = out_off_s[row];
-        const float v = HALF ? ldexpf(ldexpf(acc[tm][tn][r], -ea), -eb) + bv : acc[tm][tn][r] + bv;
-        acc[tm][tn][r] = v;
-        lsum += v;
-        if (off >= 0) p.out[(size_t)off + n] = v;
-      }
-    }
-  }
-  if (p.tile_stats) {
-    // (count, mean, M2) of this wave's 64 pixels x WN channels (one 8x8 block: inside one sample); merged per sample
-    // with Chan's formula by ln_apply_elu_kernel
-    const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));
-    float q = 0.f;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float d = acc[tm][tn][r] - mean_w;
-          q += d * d;
+          const float v = HALF ? ldexpf(ldexpf(acc[tm][tn][r], -ea), -eb) + bv : acc[tm][tn][r] + bv;
+          acc[tm][tn][r] = v;
+          lsum += v;
+          if (live) ob[(size_t)(tm * 4 + (r >> 2)) * wn + (r & 3) * p.N + tn * 32] = v;
         }
-    q = wave_sum(q);
-    const int beta = mt * NB + wblk;
-    if (lane == 0 && beta < p.nblk) {
-      float* o = p.tile_stats + ((size_t)beta * (p.N / WN) + (n0 + wn0) / WN) * 3;
-      o[0] = (float)(64 * WN);
-      o[1] = mean_w;
-      o[2] = q;
+      }
+    }
+    if (p.tile_stats) {
+      // (count, mean, M2) of this wave's 64 pixels x WN channels (one 8x8 block: inside one sample); merged per sample
+      // with Chan's formula by ln_apply_elu_kernel
+      const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));
+      float q = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[tm][tn][r] - mean_w;
+            q += d * d;
+          }
+      q = wave_sum(q);
+      if (lane == 0 && live) {
+        float* o = p.tile_stats + ((size_t)beta * (p.N / WN) + (n0 + wn0) / WN) * 3;
+        o[0] = (float)(64 * WN);
+        o[1] = mean_w;
+        o[2] = q;
+      }
+    }
+    acc_zero<TM, TN>(acc);
+    o_bx += adv_cols;
+    o_grow += adv_rows;
+    if (o_bx >= p.bw) { o_bx -= p.bw; ++o_grow; }
+  };
+
+  if constexpr (ONECH) {
+    for (int tile = mt_begin; tile < mt_end; tile += 2 * tstride) {
+      if constexpr (!PREFETCH && DB) stage_load();
+      chunk(std::integral_constant<int, 0>{}, 0);
+      epilogue(tile);
+      if (tile + tstride < mt_end) {
+        if constexpr (!PREFETCH && DB) stage_load();
+        chunk(std::integral_constant<int, 1>{}, 0);
+        epilogue(tile + tstride);
+      }
+    }
+  } else {
+    for (int tile = mt_begin; tile < mt_end; tile += tstride) {
+      for (int cc = 0; cc < nch; cc += 2) {
+        if constexpr (!PREFETCH && DB) stage_load();
+        chunk(std::integral_constant<int, 0>{}, cc);
+        if constexpr (!PREFETCH && DB) stage_load();
+        chunk(std::integral_constant<int, 1>{}, cc + 1);
+      }
+      epilogue(tile);
     }
   }
 }
@@ -291,19 +358,27 @@ __global__ void split_weights_frag_kernel(const float* __restrict__ in, u32x4* _
 
 // ---- host ---------------------------------------------------------------------------------------------------
 int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, int precision) {
-  return KH == 3 && KW == 3 && stride == 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && C % 32 == 0 && N % 32 == 0 &&
+  return KH == 3 && KW == 3 && stride == 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (C == 32 || C % 64 == 0) && N % 32 == 0 &&
          (precision == 2 || precision == 3);
 }
 
 int sgg_halo_stats_cols(int N) { return (N % 64 == 0) ? 64 : 32; }
 
-void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st) {
+void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
+  HaloParams p = p_;
   const bool half = precision == 2;
 #define SGG_HALO(NB, BN, WGM, WGN, PF)                                                                       \
   do {                                                                                                       \
-    const dim3 grid((unsigned)(sgg_cdiv(p.nblk, NB) * (p.N / BN)));                                          \
-    if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF>), grid, dim3(256), 0, st, p);  \
-    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF>), grid, dim3(256), 0, st, p);      \
+    const int mtiles = sgg_cdiv(p.nblk, NB), ntn = p.N / BN;                                                 \
+    int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       /* (tile, n-tile) pairs an XCD owns */                    \
+    int gx = per_xcd < 64 ? per_xcd : 64;           /* two resident workgroups on each of its 32 CUs */       \
+    gx = sgg_cdiv(gx, ntn) * ntn;                                                                            \
+    p.gx = gx;                                                                                               \
+    const dim3 grid((unsigned)(8 * gx));                                                                     \
+    if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true>), grid, dim3(256), 0, st, p);        \
+    else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false>), grid, dim3(256), 0, st, p);           \
+    else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true>), grid, dim3(256), 0, st, p);      \
+    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false>), grid, dim3(256), 0, st, p);                    \
   } while (0)
   if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true);
   else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false);
