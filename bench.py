@@ -25,6 +25,7 @@ import torch  # noqa: E402
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip table: Peak FP32 (matrix)
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # same table: Peak BF16 MFMA, dense
 MFMA_F16_PEAK_TFLOPS = 2500.0     # f16 MFMA runs at the bf16 rate (MI355X_MICROARCH.md, Matrix cores table)
+SUSTAINED_F16_MFMA_TFLOPS = 1635.0   # measured, random operands (see the roofline note below)
 DTYPE_NAME = {0: "f32 (native f32 MFMA)",
               2: "f32 (conv operands scaled per tensor and split into 2 fp16 pieces = 22 significant bits, 3 fp16 MFMAs per "
                  "product, f32 accumulate; error vs fp64 = native f32)",
@@ -176,7 +177,7 @@ def main():
                 a[0] += 1
                 a[1] += fl
                 a[2] += e0.elapsed_time(e1) * 1e-3
-            dom = max((s for s in per if s.startswith("conv_gather")), key=lambda s: per[s][2])
+            dom = max((s for s in per if s.startswith(("conv_gather", "conv_halo"))), key=lambda s: per[s][2])
             n, fl, sec = per[dom]
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -192,6 +193,12 @@ def main():
                                "mfma_tflops_issued": nprod * fl / sec / 1e12, "vs_native_f32_mfma_peak": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                "launches": n, "avg_launch_ms": 1e3 * sec / n, "flop_per_launch": fl / n,
                                "share_of_step_time": sec / dt}
+            if K.conv_precision in (2, 3):
+                # scripts/ubench/mfma16_peak.hip (profiles/r01_ubench_mfma16_peak.log): a register-only loop of
+                # v_mfma_f32_32x32x16_f16 on random operands sustains 1.56-1.71 PFLOP/s (the chip clocks down to 1.5-1.7 GHz
+                # under matrix load; 2.46 PFLOP/s only with all-zero operands) -> / 3 products
+                out["roofline"]["sustained_mfma_peak_measured"] = SUSTAINED_F16_MFMA_TFLOPS / nprod
+                out["roofline"]["frac_of_sustained"] = fl / sec / 1e12 / (SUSTAINED_F16_MFMA_TFLOPS / nprod)
             out["kernel_time_s"] = {s: round(v[2], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][2])}
             out["kernel_tflops"] = {s: round(v[1] / v[2] / 1e12, 2) for s, v in per.items() if v[2] > 0}
         if world == 1 and args.cpu_rows > 0:

@@ -143,9 +143,9 @@ class HipKernels:
         """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_gather.hip: dispatch_gather picks."""
         if self.conv_precision:
             tile = "128,128,2,2" if n_out % 128 == 0 else ("256,64,4,1" if n_out % 64 == 0 else "256,32,4,1")
-            return "conv_gather_bf16s_kernel<%s,%d,%s,%s>" % (tile, 3 if self.conv_precision == 6 else 2,
-                                                             "true" if presplit else "false",
-                                                             "true" if self.conv_precision == 2 else "false")
+            return "conv_gather_bf16s_kernel<%s,%d,%s,%s,32>" % (tile, 3 if self.conv_precision == 6 else 2,
+                                                                "true" if presplit else "false",
+                                                                "true" if self.conv_precision == 2 else "false")
         if n_out % 128 == 0:
             return "conv_gather3_kernel<128,128,2,2,32>"
         return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather3_kernel<256,32,4,1,32>"
@@ -233,10 +233,10 @@ class HipKernels:
         return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], k, k, stride, self.conv_precision,
                                                        layout)
 
-    def halo_symbol(self, n_out):
+    def halo_symbol(self, n_out, n_in):
         tile = "2,128,2,2" if n_out % 128 == 0 else ("4,64,4,1" if n_out % 64 == 0 else "4,32,4,1")
-        return "conv_halo3_kernel<%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
-                                                "true" if n_out % 128 == 0 else "false")
+        return "conv_halo3_kernel<%s,%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
+                                                   "true" if n_out % 128 == 0 else "false", "true" if n_in == 32 else "false")
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
@@ -244,7 +244,7 @@ class HipKernels:
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else (self.halo_symbol(d[6]) if w_split_layout == 1 else
+        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else (self.halo_symbol(d[6], d[3]) if w_split_layout == 1 else
                                                              self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
@@ -258,7 +258,7 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        sym = self.halo_symbol(d[3]) if w_split_layout == 1 else self.gather_symbol(d[3], w_split is not None)
+        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else self.gather_symbol(d[3], w_split is not None)
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),
             self._stream())), "sgg_conv2d_nhwc_dgrad")
