@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--critic-iters", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--per-shape", action="store_true", help="add per-layer conv timings to the JSON line")
     ap.add_argument("--overlap-streams", action="store_true", help="run the two encoders' forwards on two HIP streams (+3 %%)")
     ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 2, 3, 6],
                     help="conv contraction: 2 = scaled fp16 pieces, 3 products (default, f32-equivalent error), 6 = bf16 pieces, "
@@ -201,6 +202,15 @@ def main():
                 out["roofline"]["frac_of_sustained"] = fl / sec / 1e12 / (SUSTAINED_F16_MFMA_TFLOPS / nprod)
             out["kernel_time_s"] = {s: round(v[2], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][2])}
             out["kernel_tflops"] = {s: round(v[1] / v[2] / 1e12, 2) for s, v in per.items() if v[2] > 0}
+            if args.per_shape:     # per (kernel, FLOPs per launch) = per layer and direction
+                shp = {}
+                for sym, fl, e0, e1 in timing:
+                    a = shp.setdefault("%s @ %.1f GF" % (sym, fl / 1e9), [0, 0.0])
+                    a[0] += 1
+                    a[1] += e0.elapsed_time(e1) * 1e-3
+                out["per_shape"] = {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1] / args.steps, 3),
+                                        "tflops": round(float(k.split("@")[1].split()[0]) * 1e9 * v[0] / v[1] / 1e12, 1)}
+                                    for k, v in sorted(shp.items(), key=lambda kv: -kv[1][1])}
         if world == 1 and args.cpu_rows > 0:
             try:
                 ncpu = len(os.sched_getaffinity(0))

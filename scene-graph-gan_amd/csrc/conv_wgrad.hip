@@ -477,58 +477,88 @@ static void launch_slab_reduce(const float* slabs, float* out, long long n4, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Cin = 3 (conv1_1): dW[27][32] over up to 3.2 M pixels. One workgroup per pixel chunk, 216 active
-// threads, thread (k, co4) keeps 4 accumulators; dy rows and the 27-value patches go through LDS.
+// Cin = 3 (conv1_1): dW[27][32] over up to 3.2 M pixels; HBM-bound on dy (411 MB at batch 64 / 224^2).
+// Same decomposition as conv_c3_fwd_kernel: tile = 8 rows x 32 columns, thread = (column, 4 output channels); the
+// zero-padded 10 x 34 input patch sits in LDS as 16-B pixels, a thread walks its column with a rolling 3-row window and
+// accumulates its 27 x 4 partial sums in registers over all tiles of the workgroup (one coalesced 16-B dy load,
+// 3 LDS reads and 108 FMAs per pixel); one shuffle/LDS reduction per workgroup at the end, then the deterministic
+// slab reduce.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ slabs, int B, int H, int W, int pt, int pl,
-                                                            int chunk) {
-  constexpr int P = 64;  // pixels per slab
-  __shared__ __attribute__((aligned(16))) float dy_s[P * 32];
-  __shared__ float xp_s[P * 28];
-  const int tid = threadIdx.x;
-  const int npix = B * H * W;
-  const int pix_begin = blockIdx.x * chunk, pix_end = min(pix_begin + chunk, npix);
-  const int k = tid >> 3, co4 = tid & 7;  // k in 0..31 (27 used)
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int pix0 = pix_begin; pix0 < pix_end; pix0 += P) {
-    __syncthreads();
-    // dy tile: P*32 floats = 512 float4 -> 2 per thread
+                                                            float* __restrict__ slabs, int H, int W, int pt, int pl,
+                                                            int tiles_x, int tiles_y, int ntiles, int tiles_per_wg) {
+  constexpr int COUT = 32;
+  __shared__ __attribute__((aligned(16))) f32x4 patch[10 * 34];
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 27 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = tid & 7, col = tid >> 3;
+  f32x4 acc[27];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int pi = tid + 256 * j;
-      const int pix = pix0 + (pi >> 3);
+  for (int k = 0; k < 27; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int tx = t % tiles_x, t2 = t / tiles_x;
+    const int ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+    __syncthreads();
+    for (int idx = tid; idx < 10 * 34; idx += 256) {
+      const int r = idx / 34, c = idx % 34;
+      const int yy = y0 - pt + r, xx = x0 - pl + c;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pix < pix_end) v = *reinterpret_cast<const f32x4*>(dy + (size_t)pix * 32 + (pi & 7) * 4);
-      *reinterpret_cast<f32x4*>(dy_s + pi * 4) = v;
-    }
-    // patches: P*27 scalars
-    for (int e = tid; e < P * 27; e += 256) {
-      const int pr = e / 27, kk = e % 27;
-      const int pix = pix0 + pr;
-      float v = 0.f;
-      if (pix < pix_end) {
-        const int xw = pix % W;
-        const int t = pix / W;
-        const int yh = t % H;
-        const int b = t / H;
-        const int tap = kk / 3, ci = kk % 3;
-        const int yy = yh + tap / 3 - pt, xx = xw + tap % 3 - pl;
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[((size_t)(b * H + yy) * W + xx) * 3 + ci];
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+        const float* px = x + ((size_t)(b * H + yy) * W + xx) * 3;
+        v[0] = px[0]; v[1] = px[1]; v[2] = px[2];
       }
-      xp_s[pr * 28 + kk] = v;
+      patch[idx] = v;
+    }
+    // this thread's 8 dy vectors (zeros outside the image: they contribute nothing)
+    f32x4 dv[8];
+    const bool col_ok = x0 + col < W;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      dv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col_ok && y0 + r < H) dv[r] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(b * H + y0 + r) * W + x0 + col) * COUT + sub * 4);
     }
     __syncthreads();
-    if (k < 27) {
-#pragma unroll 8
-      for (int pr = 0; pr < P; ++pr) {
-        const float xv = xp_s[pr * 28 + k];
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy_s + pr * 32 + co4 * 4);
-        acc += xv * dv;
-      }
+    f32x4 rows[3][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) rows[r][kw] = patch[r * 34 + col + kw];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) rows[(r + 2) % 3][kw] = patch[(r + 2) * 34 + col + kw];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) acc[(kh * 3 + kw) * 3 + ci] += rows[(r + kh) % 3][kw][ci] * dv[r];
     }
   }
-  if (k < 27) *reinterpret_cast<f32x4*>(slabs + (size_t)blockIdx.x * 27 * 32 + k * 32 + co4 * 4) = acc;
+  // lanes with equal `sub` (stride 8) hold partial sums of the same 4 channels: combine the wave's 8 columns, then the 4 waves
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = acc[k][c];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[k][c] = v;
+    }
+  }
+  __syncthreads();
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) red[(wave * 27 + k) * 8 + lane] = acc[k];
+  }
+  __syncthreads();
+  if (tid < 27 * 8) {
+    const f32x4 v = (red[tid] + red[27 * 8 + tid]) + (red[2 * 27 * 8 + tid] + red[3 * 27 * 8 + tid]);
+    reinterpret_cast<f32x4*>(slabs + (size_t)blockIdx.x * 27 * COUT)[tid] = v;     // [k][sub*4..] == [27][32]
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -542,13 +572,11 @@ struct WgradPlan {
 static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
   WgradPlan pl;
   const long long mpix = (long long)B * Ho * Wo;
-  if (Cin == 3) {
-    pl.bmc = 27; pl.bnc = 32; pl.tiles = 1;
-    int ns = (int)((mpix + 2047) / 2048);
-    if (ns > 2048) ns = 2048;
-    if (ns < 1) ns = 1;
-    pl.chunk = (int)(((mpix + ns - 1) / ns + 63) / 64 * 64);
-    pl.nsplit = (int)((mpix + pl.chunk - 1) / pl.chunk);
+  if (Cin == 3) {        // tiles of 8 x 32 pixels, `chunk` tiles per workgroup, one slab per workgroup
+    pl.bmc = 27; pl.bnc = 32;
+    pl.tiles = B * sgg_cdiv(Ho, 8) * sgg_cdiv(Wo, 32);
+    pl.chunk = sgg_cdiv(pl.tiles, 1024);
+    pl.nsplit = sgg_cdiv(pl.tiles, pl.chunk);
     pl.ws_bytes = (size_t)pl.nsplit * 27 * 32 * sizeof(float);
     return pl;
   }
@@ -616,8 +644,8 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   }
   if (Cin == 3) {
     SGG_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && Cout == 32, "sgg_conv2d_nhwc_wgrad: Cin=3 path needs 3x3 s1 Cout=32");
-    hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, B, Hi, Wi, pad_t,
-                       pad_l, pl.chunk);
+    hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, Hi, Wi, pad_t, pad_l,
+                       sgg_cdiv(Wo, 32), sgg_cdiv(Ho, 8), pl.tiles, pl.chunk);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3)");
     launch_slab_reduce((const float*)workspace, dw, nout / 4, pl.nsplit, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3 reduce)");

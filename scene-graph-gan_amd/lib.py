@@ -244,7 +244,7 @@ class HipKernels:
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel<32>" if d[3] == 3 else (self.halo_symbol(d[6], d[3]) if w_split_layout == 1 else
+        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3]) if w_split_layout == 1 else
                                                              self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)

@@ -100,8 +100,8 @@ class Trunk:
             K.fill(self.amax[0], 0.0)
         for j, lay in enumerate(self.layers):
             ws = lay["ws_fwd"] if (lay["ws_fwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
-            ts = lay["tstats"] if (lay["tstats"] is not None and ws is not None
-                                   and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])) else None
+            ts = lay["tstats"] if (lay["tstats"] is not None and (ws is not None or lay["cin"] == 3)
+                                   and (lay["cin"] == 3 or lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"]))) else None
             if ws is not None or self._f16() or ts is not None:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j), ts,
                            lay["ws_layout"] if ws is not None else 0)

@@ -419,6 +419,30 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
         hip.conv_precision = old
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32), (3, 13, 45), (1, 8, 64)])
+def test_conv_c3_tile_stats(hip, ref, shape):
+    """conv1_1 (Cin = 3): output vs fp64 and the per-tile LayerNorm partials (ragged tiles at the right / bottom edge)."""
+    B, H, W = shape
+    x, w, b = rnd((B, H, W, 3), 70), rnd((3, 3, 3, 32), 71, 0.2), rnd((32,), 72, 0.5)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    nts = hip.conv_tile_stats_count((B, H, W, 32), 3, 3, 1, 0)
+    assert nts == -(-H // 8) * -(-W // 32)
+    ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+    y = torch.full((B, H, W, 32), float("nan"), device="cuda")
+    hip.conv_fwd(xd, wd, wd, bd, y, 1, tile_stats=ts)
+    y_ref = torch.empty((B, H, W, 32), dtype=torch.float64)
+    ref.conv_fwd(x.double(), w.double(), None, b.double(), y_ref, 1)
+    close(y, y_ref, rtol=2e-6, what="conv1_1 forward")
+    assert abs(float(ts[:, :, 0].sum()) - B * H * W * 32) < 0.5
+    gamma, beta = dev(1.0 + rnd((32,), 73, 0.2)), dev(rnd((32,), 74, 0.2))
+    a1, a2 = torch.empty_like(y), torch.empty_like(y)
+    st1, st2 = torch.empty((B, 2), device="cuda"), torch.empty((B, 2), device="cuda")
+    hip.ln_elu_fwd(y, gamma, beta, a1, st1, tile_stats=ts)
+    hip.ln_elu_fwd(y, gamma, beta, a2, st2)
+    close(st1, st2.cpu(), rtol=1e-6, what="stats from the conv1_1 epilogue vs statistics pass")
+    close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+
+
 def test_conv_halo_rejects_bad_shapes(hip):
     from sgg_amd.lib import SggError
     if hip.conv_precision not in (2, 3):
