@@ -12,6 +12,7 @@
 // Dual tensors are two planes (real, dual). For cotangent tensors: real plane = cotangent of the tangent,
 // dual plane = cotangent of the primal (dual.h).
 #include "dual.h"
+#include <stdlib.h>
 
 #define HEAD_LN_EPS 1e-12f
 #define NUM_UNITS 512
@@ -152,6 +153,93 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(const float* __restr
     float s = accumulate ? dP[(size_t)b * L + l] : 0.f;
     for (int k = 0; k < npass; ++k) s += Sc<T>::pcot(da_s[k * L + l]);
     dP[(size_t)b * L + l] = s;
+  }
+}
+
+// Split form of the same backward for full-size feature maps: with one workgroup per image only B (= 64) workgroups
+// stream ctx / dctx (1.2 TB/s).  Phase A, grid (B, LS): workgroup (b, j) owns the locations l = j, j + LS, ... of image b:
+// dctx rows and the raw dalpha_l = <dz, ctx_l> (parked in `de`).  Phase B, grid B: softmax backward over the L
+// locations of each row and dP.  No atomics; same summation order as the fused kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_step_bwd_ctx_kernel(const float* __restrict__ ctx, const float* __restrict__ al_r,
+                                                                const float* __restrict__ al_d, const float* __restrict__ dz_r,
+                                                                const float* __restrict__ dz_d, int lddz, float* __restrict__ de_r,
+                                                                float* __restrict__ de_d, float* __restrict__ dctx, int R, int B,
+                                                                int L, int C, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int npass = R / B;
+  T* dz_s = reinterpret_cast<T*>(sm);         // [npass][C]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = 0; k < npass; ++k) {
+    const int r = b + k * B;
+    for (int c = tid; c < C; c += 256) dz_s[k * C + c] = Sc<T>::ld(dz_r, dz_d, (size_t)r * lddz + c);
+  }
+  __syncthreads();
+  const float* cb = ctx + (size_t)b * L * C;
+  float* db = dctx + (size_t)b * L * C;
+  for (int l = blockIdx.y * 4 + wave; l < L; l += 4 * gridDim.y) {
+    T dot[ATTN_MAX_PASS], a[ATTN_MAX_PASS];
+#pragma unroll
+    for (int k = 0; k < ATTN_MAX_PASS; ++k) {
+      dot[k] = Sc<T>::zero();
+      a[k] = k < npass ? Sc<T>::ld(al_r, al_d, (size_t)(b + k * B) * L + l) : Sc<T>::zero();
+    }
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(cb + (size_t)l * C + c);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (accumulate) acc = *reinterpret_cast<const f32x4*>(db + (size_t)l * C + c);
+#pragma unroll
+      for (int k = 0; k < ATTN_MAX_PASS; ++k) {
+        if (k < npass) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const T dzv = dz_s[k * C + c + q];
+            dot[k] += dzv * cv[q];
+            acc[q] += Sc<T>::pcot(a[k] * dzv);
+          }
+        }
+      }
+      *reinterpret_cast<f32x4*>(db + (size_t)l * C + c) = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < ATTN_MAX_PASS; ++k) {
+      if (k < npass) {
+        const T d = wave_sum(dot[k]);
+        if (lane == 0) Sc<T>::st(de_r, de_d, (size_t)(b + k * B) * L + l, d);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_step_bwd_softmax_kernel(const float* __restrict__ al_r, const float* __restrict__ al_d,
+                                                                    float* __restrict__ de_r, float* __restrict__ de_d,
+                                                                    float* __restrict__ dP, int R, int B, int L, int accumulate) {
+  __shared__ float red[4];
+  const int npass = R / B;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float dp[8];                                // locations tid, tid + 256, ... (L <= 2048)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dp[j] = 0.f;
+  for (int k = 0; k < npass; ++k) {
+    const int r = b + k * B;
+    T s = Sc<T>::zero();
+    for (int l = tid; l < L; l += 256) s += Sc<T>::ld(de_r, de_d, (size_t)r * L + l) * Sc<T>::ld(al_r, al_d, (size_t)r * L + l);
+    s = block_sum_256(s, red);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int l = tid + 256 * j;
+      if (l < L) {
+        const T de = Sc<T>::ld(al_r, al_d, (size_t)r * L + l) * (Sc<T>::ld(de_r, de_d, (size_t)r * L + l) - s);
+        Sc<T>::st(de_r, de_d, (size_t)r * L + l, de);
+        dp[j] += Sc<T>::pcot(de);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int l = tid + 256 * j;
+    if (l < L) dP[(size_t)b * L + l] = (accumulate ? dP[(size_t)b * L + l] : 0.f) + dp[j];
   }
 }
 
@@ -457,6 +545,25 @@ extern "C" int sgg_attn_step_bwd(const float* ctx, const float* alpha, const flo
   const int npass = R / B;
   SGG_CHECK_ARG(npass <= ATTN_MAX_PASS, "sgg_attn_step_bwd: at most %d rows per image (got %d)", ATTN_MAX_PASS, npass);
   hipStream_t st = (hipStream_t)stream;
+  // full-size feature maps: split the locations of an image over several workgroups (see attn_step_bwd_ctx_kernel)
+  static const bool split_on = [] { const char* e = getenv("SGG_ATTN_SPLIT"); return !(e && e[0] == '0'); }();   // (A/B measurements)
+  const int ls = (split_on && B < 256 && L >= 64 && L <= 2048) ? (512 / B < L / 8 ? 512 / B : L / 8) : 1;
+  if (ls > 1) {
+    if (alpha_dual) {
+      SGG_CHECK_ARG(dz_dual && de_dual, "sgg_attn_step_bwd: dual pointers missing");
+      hipLaunchKernelGGL(attn_step_bwd_ctx_kernel<Dual>, dim3(B, ls), dim3(256), (size_t)npass * C * sizeof(Dual), st, ctx, alpha,
+                         alpha_dual, dz, dz_dual, lddz, de, de_dual, dctx, R, B, L, C, accumulate);
+      hipLaunchKernelGGL(attn_step_bwd_softmax_kernel<Dual>, dim3(B), dim3(256), 0, st, alpha, alpha_dual, de, de_dual, dP, R, B, L,
+                         accumulate);
+    } else {
+      hipLaunchKernelGGL(attn_step_bwd_ctx_kernel<float>, dim3(B, ls), dim3(256), (size_t)npass * C * sizeof(float), st, ctx, alpha,
+                         nullptr, dz, nullptr, lddz, de, nullptr, dctx, R, B, L, C, accumulate);
+      hipLaunchKernelGGL(attn_step_bwd_softmax_kernel<float>, dim3(B), dim3(256), 0, st, alpha, nullptr, de, nullptr, dP, R, B, L,
+                         accumulate);
+    }
+    SGG_LAUNCH_CHECK("sgg_attn_step_bwd");
+    return SGG_OK;
+  }
   if (alpha_dual) {
     SGG_CHECK_ARG(dz_dual && de_dual, "sgg_attn_step_bwd: dual pointers missing");
     const size_t smb = (size_t)npass * (C + 2 * L) * sizeof(Dual);
