@@ -19,6 +19,24 @@
 #include <type_traits>
 #include <stdlib.h>
 
+// -DSGG_HALO_PROFILE (scripts/build_prof_lib.sh): per-wave cycle accounting of the tap loop with explicit waits, summed into
+// sgg_halo_prof[] by wave 0 of every workgroup: {total, wait for B fragments (vmcnt), A fragment reads (issue + lgkmcnt),
+// MFMA issue, chunk boundary (patch write + barrier), epilogue, waves}.
+#ifdef SGG_HALO_PROFILE
+__device__ unsigned long long sgg_halo_prof[8];
+extern "C" int sgg_halo_prof_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sgg_halo_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sgg_halo_prof), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define PROF(...) __VA_ARGS__
+#else
+#define PROF(...)
+#endif
+
 #define HALO_PITCH 12
 #define HALO_BLKB (10 * HALO_PITCH * 64)   // bytes of one plane of one block's patch
 
@@ -64,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     eb = scale_exp_from_amax(*p.amax_w);
   }
   const float sa = ldexpf(1.f, ea);
+  PROF(unsigned long long pc_vm = 0, pc_lds = 0, pc_mfma = 0, pc_chunk = 0, pc_epi = 0; const unsigned long long pc_t0 = __builtin_readcyclecounter();)
 
   // ---- staging plan (static per thread): item -> offset relative to its block's patch origin, border bits, LDS offset ----
   unsigned it_rel[NPASS];
@@ -179,8 +198,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   // waited for the loads it had just issued: the whole L2 latency exposed per tap.)
   // (Reading the A fragments of tap t+1 between the two k-steps of tap t - software pipelining inside the wave - was
   //  measured: no gain, 32 more VGPRs.)
-  u32x4 a[TM][2][P];
-  auto read_a = [&](int tap) {
+  u32x4 a[2][TM][2][P];
+  auto read_a = [&](auto buf_c, int tap) {
+    constexpr int buf = decltype(buf_c)::value;
     const int kh = tap / 3, kw = tap % 3;
     const int dyy = p.flip ? 2 - kh : kh, dxx = p.flip ? 2 - kw : kw;
     // (opaque to the optimiser: otherwise the 36 per-tap LDS addresses are hoisted out of the chunk loop and spilled,
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
-          a[tm][ks][pp] = *reinterpret_cast<const u32x4*>(row + pp * PLANEB + (((2 * ks + h) ^ hs) << 4));
+          a[buf][tm][ks][pp] = *reinterpret_cast<const u32x4*>(row + pp * PLANEB + (((2 * ks + h) ^ hs) << 4));
     }
   };
   auto mma_kstep = [&](auto par_c, auto ks_c) {
@@ -207,9 +227,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         f32x16 d = acc[tm][tn];
-        d = mfma16<HALF>(a[tm][ks][1], rb[par][tn][ks][0], d);
-        d = mfma16<HALF>(a[tm][ks][0], rb[par][tn][ks][1], d);
-        d = mfma16<HALF>(a[tm][ks][0], rb[par][tn][ks][0], d);
+        d = mfma16<HALF>(a[par][tm][ks][1], rb[par][tn][ks][0], d);
+        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][1], d);
+        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][0], d);
         acc[tm][tn] = d;
       }
   };
@@ -219,19 +239,40 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     load_b(std::integral_constant<int, par ^ 1>{}, tap == 8 ? ncc : cc, tap == 8 ? 0 : tap + 1);
     if constexpr (PREFETCH && tap == 6) stage_load();
     __builtin_amdgcn_sched_barrier(0);
-    read_a(tap);
+    // DB: the next chunk's patch (loads issued at tap 6) is split and written to the other buffer inside the last tap's
+    // scheduling region, so its ~170 VALU instructions issue in the shadow of this tap's MFMAs
+    if constexpr (DB && PREFETCH && tap == 8) stage_write(lds + (cur ^ 1) * (P * PLANEB));
+#ifdef SGG_HALO_PROFILE
+    const unsigned long long q0 = __builtin_readcyclecounter();
+    if constexpr (PREFETCH && (tap == 6 || tap == 7)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    const unsigned long long q1 = __builtin_readcyclecounter();
+    pc_vm += q1 - q0;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    // A fragments of tap t+1 are read between the two k-steps of tap t (the in-kernel profile shows 11 % of a wave's time
+    // in issue + wait of these reads when they sit in front of the MFMAs)
+    PROF(const unsigned long long q2 = __builtin_readcyclecounter();)
     mma_kstep(par_c, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    PROF(const unsigned long long q3 = __builtin_readcyclecounter();)
+    if constexpr (tap < 8) read_a(std::integral_constant<int, par ^ 1>{}, tap + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PROF(const unsigned long long q4 = __builtin_readcyclecounter(); pc_lds += q4 - q3;)
     mma_kstep(par_c, std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
+    PROF(pc_mfma += (__builtin_readcyclecounter() - q4) + (q3 - q2);)
   };
   auto chunk = [&](auto par0_c, int cc) {
     constexpr int par0 = decltype(par0_c)::value;
+    read_a(par0_c, 0);
 #define SGG_TAP(T) tap_body(std::integral_constant<int, (par0 + T) & 1>{}, std::integral_constant<int, T>{}, cc)
     SGG_TAP(0); SGG_TAP(1); SGG_TAP(2); SGG_TAP(3); SGG_TAP(4); SGG_TAP(5); SGG_TAP(6); SGG_TAP(7); SGG_TAP(8);
 #undef SGG_TAP
     // next chunk (of this tile or the first of the next tile): replace the resident patch
+    PROF(const unsigned long long qc = __builtin_readcyclecounter();)
     if constexpr (DB) {
-      stage_write(lds + (cur ^ 1) * (P * PLANEB));        // nobody reads the other buffer since the previous barrier
+      if constexpr (!PREFETCH) stage_write(lds + (cur ^ 1) * (P * PLANEB));   // nobody reads the other buffer since the previous barrier
       cur ^= 1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -243,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    PROF(pc_chunk += __builtin_readcyclecounter() - qc;)
   };
 
   // this wave's output block: global block row and column, advanced by NB per tile
@@ -252,7 +294,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     o_grow = beta / p.bw;
     o_bx = beta % p.bw;
   }
-  const int o_lane = (4 * h * p.N) + n0 + wn0 + (lane & 31);
+  const unsigned o_lane_b = (unsigned)((4 * h * p.N) + n0 + wn0 + (lane & 31)) * 4u;     // per-lane byte offset inside a block
+  const float us_a = ldexpf(1.f, -ea), us_b = ldexpf(1.f, -eb);
+  // (loaded once: a bias load inside the tile epilogue would wait (vmcnt(0)) for every prefetch in flight)
+  float bias_v[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) bias_v[tn] = p.bias ? p.bias[n0 + wn0 + tn * 32 + acc_col(lane)] : 0.f;
   const int wn = p.W * p.N;
 
   stage_load();
@@ -262,24 +309,34 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   __builtin_amdgcn_s_barrier();
 
   auto epilogue = [&](int tile) {
+    PROF(const unsigned long long qe = __builtin_readcyclecounter();)
     // ---- tile epilogue: unscale, + bias, store; optionally this wave's LayerNorm partial statistics; clear ----------
     const int beta = tile * NB + wblk;
     const bool live = beta < p.nblk;
-    float* ob = p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.N + o_lane;
+    // uniform (scalar) pointer to the block's first pixel; per store: scalar row/pixel offset + one per-lane byte offset
+    const char* ob = reinterpret_cast<const char*>(p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.N);
     float lsum = 0.f;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const float bv = p.bias ? p.bias[n0 + wn0 + tn * 32 + acc_col(lane)] : 0.f;
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = HALF ? ldexpf(ldexpf(acc[tm][tn][r], -ea), -eb) + bv : acc[tm][tn][r] + bv;
+          // (two exact power-of-two factors: |ea|, |eb| <= 100 keeps each one a normal float)
+          const float v = HALF ? fmaf(acc[tm][tn][r] * us_a, us_b, bias_v[tn]) : acc[tm][tn][r] + bias_v[tn];
           acc[tm][tn][r] = v;
           lsum += v;
-          if (live) ob[(size_t)(tm * 4 + (r >> 2)) * wn + (r & 3) * p.N + tn * 32] = v;
         }
-      }
+    if (live) {        // one uniform branch around all stores (a branch per store costs ~64 jumps per tile)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const size_t so = ((size_t)(tm * 4 + (r >> 2)) * wn + (size_t)(r & 3) * p.N + tn * 32) * sizeof(float);   // scalar
+            *reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b) = acc[tm][tn][r];
+          }
     }
     if (p.tile_stats) {
       // (count, mean, M2) of this wave's 64 pixels x WN channels (one 8x8 block: inside one sample); merged per sample
@@ -307,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     o_bx += adv_cols;
     o_grow += adv_rows;
     if (o_bx >= p.bw) { o_bx -= p.bw; ++o_grow; }
+    PROF(pc_epi += __builtin_readcyclecounter() - qe;)
   };
 
   if constexpr (ONECH) {
@@ -331,6 +389,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       epilogue(tile);
     }
   }
+#ifdef SGG_HALO_PROFILE
+  if (tid == 0) {
+    atomicAdd(&sgg_halo_prof[0], __builtin_readcyclecounter() - pc_t0);
+    atomicAdd(&sgg_halo_prof[1], pc_vm);
+    atomicAdd(&sgg_halo_prof[2], pc_lds);
+    atomicAdd(&sgg_halo_prof[3], pc_mfma);
+    atomicAdd(&sgg_halo_prof[4], pc_chunk);
+    atomicAdd(&sgg_halo_prof[5], pc_epi);
+    atomicAdd(&sgg_halo_prof[6], 1ull);
+  }
+#endif
 }
 
 // f32 [taps][N][C] -> two 16-bit planes in MFMA B-fragment order [tap][C/32][N/32][k-step][plane][lane] x 16 B:
@@ -382,7 +451,7 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
   } while (0)
   if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true);
   else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false);
-  else SGG_HALO(4, 32, 4, 1, false);
+  else SGG_HALO(4, 32, 4, 1, true);
 #undef SGG_HALO
 }
 

@@ -73,10 +73,12 @@ class SggError(RuntimeError):
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
-    """Load libsgg_hip.so and bind every declared symbol. Raises if the library or a symbol is missing."""
+    """Load libsgg_hip.so and bind every declared symbol. Raises if the library or a symbol is missing.
+    SGG_HIP_LIB overrides the path (instrumented builds, scripts/build_prof_lib.sh)."""
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("SGG_HIP_LIB", path)
     if not os.path.exists(path):
         raise SggError("libsgg_hip.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)" % path)
@@ -236,7 +238,7 @@ class HipKernels:
     def halo_symbol(self, n_out, n_in):
         tile = "2,128,2,2" if n_out % 128 == 0 else ("4,64,4,1" if n_out % 64 == 0 else "4,32,4,1")
         return "conv_halo3_kernel<%s,%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
-                                                   "true" if n_out % 128 == 0 else "false", "true" if n_in == 32 else "false")
+                                                   "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false", "true" if n_in == 32 else "false")
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""

@@ -11,6 +11,8 @@ reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
 mode = sys.argv[8] if len(sys.argv) > 8 else "fwd"
 K = HipKernels("cuda:0")
 x = torch.randn((B, H, H, Ci), device="cuda")
+if os.environ.get("SGG_PROF_ZERO") == "1": x.zero_()
+if os.environ.get("SGG_PROF_ZERO") == "2": x.fill_(1.0)
 w = torch.randn((k, k, Ci, Co), device="cuda") * 0.05
 b = torch.randn((Co,), device="cuda")
 Ho = same_pads(H, k, s)[0]
