@@ -35,8 +35,9 @@ struct WgradHaloPlan {
   int nslabs;           // nsplit * spw
   size_t ws_bytes;
 };
-// returns 1 and fills the plan if the shape is served (3x3, stride 1, H % 8 == W % 8 == 0, channels % 32 == 0)
+// returns 1 and fills the plan if the shape is served (H, W = the dy grid, both % 8 == 0; 3x3 stride 1 or 5x5 stride 2; channels % 32 == 0)
 int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradHaloPlan* pl);
 // writes pl.nslabs partial dW slabs [slab][9][Cin][Cout] (unscaled f32) into `slabs`
-void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int precision,
-                           const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl, hipStream_t st);
+void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,
+                           int pad_t, int pad_l, int precision, const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl,
+                           hipStream_t st);

@@ -598,7 +598,8 @@ extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, i
                                                         int KW) {
   size_t need = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW).ws_bytes;
   WgradHaloPlan hp;     // (precision and stride are not known here: upper bound over both kernels)
-  if (Hi == Ho && Wi == Wo && sgg_wgrad_halo_plan(B, Hi, Wi, Cin, Cout, KH, KW, 1, &hp) && hp.ws_bytes > need) need = hp.ws_bytes;
+  const int st_guess = (Hi == Ho && Wi == Wo) ? 1 : ((Hi == 2 * Ho && Wi == 2 * Wo) ? 2 : 0);
+  if (st_guess && Cin != 3 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, st_guess, &hp) && hp.ws_bytes > need) need = hp.ws_bytes;
   return need;
 }
 
@@ -629,14 +630,14 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   }
   const long long nout = (long long)KH * KW * Cin * Cout;
   WgradHaloPlan hp;
-  if ((precision == 2 || precision == 3) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho && Wi == Wo && wgrad_halo_enabled() &&
-      sgg_wgrad_halo_plan(B, Hi, Wi, Cin, Cout, KH, KW, stride, &hp)) {
+  if ((precision == 2 || precision == 3) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho * stride && Wi == Wo * stride &&
+      wgrad_halo_enabled() && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp)) {
     // halo-resident kernel: the nine taps of a channel chunk from one LDS-resident patch (conv_wgrad_halo.hip)
     if (!workspace || workspace_bytes < hp.ws_bytes) {
       sgg_set_error("sgg_conv2d_nhwc_wgrad: workspace too small (%zu < %zu)", workspace_bytes, hp.ws_bytes);
       return SGG_ERR_WORKSPACE;
     }
-    sgg_wgrad_halo_launch(x, dy, (float*)workspace, B, Hi, Wi, Cin, Cout, precision, amax_x, amax_dy, hp, st);
+    sgg_wgrad_halo_launch(x, dy, (float*)workspace, B, Ho, Wo, Cin, Cout, stride, pad_t, pad_l, precision, amax_x, amax_dy, hp, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo)");
     launch_slab_reduce((const float*)workspace, dw, nout / 4, hp.nslabs, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo reduce)");

@@ -30,15 +30,24 @@ struct WgradHaloParams {
   float* slabs;
   const float* amax_x;
   const float* amax_dy;
-  int H, W, C, N;         // C = Cin, N = Cout
+  int H, W, C, N;         // dy grid (= output grid of the convolution); C = Cin, N = Cout
+  int Hx, Wx;             // x grid (= H, W for stride 1; 2H, 2W for the stride-2 classes)
+  int sxy;                // stride (1 or 2)
+  int cy, cx;             // this launch's parity class: x row = sxy * i + cy for sub-grid row i (0 for stride 1)
+  int a0y, a0x;           // first sub-grid offset of the class's taps (-1 or 0): tap (ia, ib) reads sub-grid pixel (oy + a0y + ia, ox + a0x + ib)
+  int kh0, kw0, kstep;    // kernel tap of (ia, ib) = (kh0 + kstep*ia, kw0 + kstep*ib)
+  int KWt, taps_total;    // kernel width (3 / 5) and KH*KW: slab layout [slab][taps_total][Cin][Cout]
   int bh, bw, nblk;       // 8x8 blocks per image (rows, cols) and in total
   int pairs_n;            // Cout chunks
   int stages;             // stages per workgroup (NBS blocks each)
   unsigned x_bytes, dy_bytes;
 };
 
-template <int CT, int NT, bool HALF, bool PREF>
+// NKH x NKW: taps of the launch (3x3 for the stride-1 kernel; 3x3 / 3x2 / 2x3 / 2x2 for the four parity classes of a 5x5
+// stride-2 kernel, each a stride-1 problem on the sub-sampled x grid).
+template <int CT, int NT, bool HALF, bool PREF, int NKH, int NKW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParams p) {
+  constexpr int NTAP = NKH * NKW;
   constexpr int P = 2;
   constexpr int NBS = (CT == 2) ? 1 : 2;                 // blocks per stage
   constexpr int KSW = (CT == 1 && NT == 1) ? 2 : 4;      // 16-pixel MFMA steps per wave and block
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
       const int csub = i / 400, r = i % 400;
       const int px = r >> 2, c4 = r & 3;
       const int ry = px / 10, rx = px % 10;
-      it_rel[j] = (unsigned)(((ry * p.W + rx) * p.C + csub * 32 + c4 * 8) * 4);
+      it_rel[j] = (unsigned)(((ry * p.sxy * p.Wx + rx * p.sxy) * p.C + csub * 32 + c4 * 8) * 4);
       const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
       it_lds[j] = ((blk * CT + csub) * XSUB + (ry * 12 + rx) * 64 + c4 * 16) | (bits << 20) | ((i < XI) << 24);
     } else {
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
     for (int blk = 0; blk < NBS; ++blk) {
       const bool dead = (next_beta + blk >= p.nblk) | (next_beta + blk >= blk_begin + p.stages * NBS);
       const int by = cy[blk], bx = cx[blk];
-      const unsigned xbase = (unsigned)((((cb[blk] * p.H + by * 8 - 1) * p.W + bx * 8 - 1) * p.C + c0) * 4);
+      const unsigned xbase = (unsigned)((((cb[blk] * p.Hx + (by * 8 - 1) * p.sxy + p.cy) * p.Wx + (bx * 8 - 1) * p.sxy + p.cx) * p.C + c0) * 4);
       const unsigned dbase = (unsigned)((((cb[blk] * p.H + by * 8) * p.W + bx * 8) * p.N + n0) * 4);
       const int bbits = (by == 0) | ((by == p.bh - 1) << 1) | ((bx == 0) << 2) | ((bx == p.bw - 1) << 3);
 #pragma unroll
@@ -159,12 +168,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   // lane 4q+pch of the group addresses pixel q (lo) / q+4 (hi) of the k half's row and channels 4pch..4pch+3
   const int g = lane >> 4, q = (lane >> 2) & 3, pch = lane & 3;
   const int choff = ((g & 1) * 2 + (pch >> 1)) * 16 + (pch & 1) * 8;
-  const unsigned char* a_base = x_s + (wblk * CT + ci_t) * XSUB + ((2 * ks0 + (g >> 1)) * 12 + q) * 64 + choff;
+  const unsigned char* a_base = x_s + (wblk * CT + ci_t) * XSUB + ((2 * ks0 + (g >> 1) + p.a0y + 1) * 12 + q + p.a0x + 1) * 64 + choff;
   const unsigned char* b_base = d_s + (wblk * NT + co_t) * DSUB + ((2 * ks0 + (g >> 1)) * 8 + q) * 64 + choff;
 
-  f32x16 acc[9];
+  f32x16 acc[NTAP];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -179,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
         b[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
       }
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int kh = tap / 3, kw = tap % 3;
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const int kh = tap / NKW, kw = tap % NKW;
         u32x4 a[P];
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) {
@@ -214,23 +223,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   }
 
   // ---- partial slab: [slab][tap][Cin][Cout] -------------------------------------------------------------------
-  float* o = p.slabs + (size_t)(split * SPW + sw) * 9 * p.C * p.N;
+  float* o = p.slabs + (size_t)(split * SPW + sw) * p.taps_total * p.C * p.N;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int tap = 0; tap < NTAP; ++tap)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = c0 + ci_t * 32 + acc_row(r, lane);
       const int co = n0 + co_t * 32 + acc_col(lane);
       const float v = acc[tap][r];
-      o[((size_t)tap * p.C + ci) * p.N + co] = HALF ? ldexpf(ldexpf(v, -ea), -eb) : v;
+      const int ktap = (p.kh0 + p.kstep * (tap / NKW)) * p.KWt + p.kw0 + p.kstep * (tap % NKW);
+      o[((size_t)ktap * p.C + ci) * p.N + co] = HALF ? ldexpf(ldexpf(v, -ea), -eb) : v;
     }
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
+// H, W: the dy grid.  Served: 3x3 stride 1 (x grid = dy grid) and 5x5 stride 2 with an even x grid (= 2H x 2W, SAME pads
+// (1, 2)); H % 8 == W % 8 == 0, channels % 32 == 0.
 int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradHaloPlan* pl) {
-  if (!(KH == 3 && KW == 3 && stride == 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cin % 32 == 0 && Cout % 32 == 0 && B > 0))
+  const bool k3 = KH == 3 && KW == 3 && stride == 1, k5 = KH == 5 && KW == 5 && stride == 2;
+  if (!((k3 || k5) && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cin % 32 == 0 && Cout % 32 == 0 && B > 0)) return 0;
+  if ((size_t)B * H * W * stride * stride * Cin * sizeof(float) >= 0x80000000ull || (size_t)B * H * W * Cout * sizeof(float) >= 0x80000000ull)
     return 0;
-  if ((size_t)B * H * W * Cin * sizeof(float) >= 0x80000000ull || (size_t)B * H * W * Cout * sizeof(float) >= 0x80000000ull) return 0;
   if (Cin % 64 == 0 && Cout % 64 == 0) { pl->ct = 2; pl->nt = 2; }
   else if (Cout % 64 == 0) { pl->ct = 1; pl->nt = 2; }
   else { pl->ct = 1; pl->nt = 1; }
@@ -246,27 +259,53 @@ int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, 
   pl->stages = (total_stages + ns - 1) / ns;
   pl->nsplit = (total_stages + pl->stages - 1) / pl->stages;
   pl->nslabs = pl->nsplit * pl->spw;
-  pl->ws_bytes = (size_t)pl->nslabs * 9 * Cin * Cout * sizeof(float);
+  pl->ws_bytes = (size_t)pl->nslabs * KH * KW * Cin * Cout * sizeof(float);
   return 1;
 }
 
-void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int precision,
-                           const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl, hipStream_t st) {
-  WgradHaloParams p;
-  p.x = x; p.dy = dy; p.slabs = slabs; p.amax_x = amax_x; p.amax_dy = amax_dy;
-  p.H = H; p.W = W; p.C = Cin; p.N = Cout; p.bh = H / 8; p.bw = W / 8; p.nblk = B * p.bh * p.bw;
-  p.pairs_n = pl.pairs_n; p.stages = pl.stages;
-  p.x_bytes = (unsigned)((size_t)B * H * W * Cin * sizeof(float));
-  p.dy_bytes = (unsigned)((size_t)B * H * W * Cout * sizeof(float));
+template <int NKH, int NKW>
+static void wgrad_halo_launch_class(const WgradHaloParams& p, const WgradHaloPlan& pl, bool half, hipStream_t st) {
   const dim3 grid(pl.nsplit, pl.pairs);
-  const bool half = precision == 2;
-#define SGG_WH(CT, NT, PF)                                                                                        \
-  do {                                                                                                            \
-    if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF>), grid, dim3(256), 0, st, p);           \
-    else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF>), grid, dim3(256), 0, st, p);               \
+#define SGG_WH(CT, NT, PF)                                                                                          \
+  do {                                                                                                              \
+    if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF, NKH, NKW>), grid, dim3(256), 0, st, p);   \
+    else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF, NKH, NKW>), grid, dim3(256), 0, st, p);       \
   } while (0)
   if (pl.ct == 2) SGG_WH(2, 2, true);
   else if (pl.nt == 2) SGG_WH(1, 2, false);
   else SGG_WH(1, 1, true);
 #undef SGG_WH
+}
+
+// stride: 1 (3x3) or 2 (5x5, one launch per parity class of the taps); pad_t / pad_l: SAME padding before
+void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,
+                           int pad_t, int pad_l, int precision, const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl,
+                           hipStream_t st) {
+  WgradHaloParams p;
+  p.x = x; p.dy = dy; p.slabs = slabs; p.amax_x = amax_x; p.amax_dy = amax_dy;
+  p.H = H; p.W = W; p.C = Cin; p.N = Cout; p.bh = H / 8; p.bw = W / 8; p.nblk = B * p.bh * p.bw;
+  p.Hx = H * stride; p.Wx = W * stride; p.sxy = stride;
+  p.pairs_n = pl.pairs_n; p.stages = pl.stages;
+  p.x_bytes = (unsigned)((size_t)B * p.Hx * p.Wx * Cin * sizeof(float));
+  p.dy_bytes = (unsigned)((size_t)B * H * W * Cout * sizeof(float));
+  const bool half = precision == 2;
+  if (stride == 1) {
+    p.cy = p.cx = 0; p.a0y = p.a0x = -1; p.kh0 = p.kw0 = 0; p.kstep = 1; p.KWt = 3; p.taps_total = 9;
+    wgrad_halo_launch_class<3, 3>(p, pl, half, st);
+    return;
+  }
+  p.kstep = 2; p.KWt = 5; p.taps_total = 25;
+  for (int cy = 0; cy < 2; ++cy)
+    for (int cx = 0; cx < 2; ++cx) {
+      // taps kh with (kh - pad_t) mod 2 == cy: kh0 = first such tap, sub-grid offset a0 = floor((kh0 - pad_t - cy) / 2) + ... = (kh0 - pad_t - cy) / 2
+      const int kh0 = (pad_t + cy) % 2, kw0 = (pad_l + cx) % 2;
+      p.cy = cy; p.cx = cx; p.kh0 = kh0; p.kw0 = kw0;
+      p.a0y = (kh0 - pad_t - cy) / 2;           // exact: kh0 - pad_t - cy is even (and <= 0)
+      p.a0x = (kw0 - pad_l - cx) / 2;
+      const int nkh = (5 - kh0 + 1) / 2, nkw = (5 - kw0 + 1) / 2;
+      if (nkh == 3 && nkw == 3) wgrad_halo_launch_class<3, 3>(p, pl, half, st);
+      else if (nkh == 3) wgrad_halo_launch_class<3, 2>(p, pl, half, st);
+      else if (nkw == 3) wgrad_halo_launch_class<2, 3>(p, pl, half, st);
+      else wgrad_halo_launch_class<2, 2>(p, pl, half, st);
+    }
 }

@@ -50,6 +50,10 @@ CONV_CASES = [
     (1, 4, 4, 512, 512, 5, 2),
     (3, 20, 20, 64, 64, 3, 1),      # M = 1200: several tiles + ragged last tile
     (2, 10, 10, 3, 32, 3, 1),       # conv1_1 path (Cin = 3)
+    (2, 16, 16, 32, 32, 5, 2),      # output grid 8x8: wgrad through the halo kernel's four stride-2 parity classes
+    (2, 32, 16, 32, 64, 5, 2),
+    (3, 16, 32, 64, 128, 5, 2),
+    (1, 16, 16, 128, 128, 5, 2),
 ]
 
 
