@@ -45,6 +45,8 @@ int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; ze
  * conv3_2) in precision 2 / 3: sgg_conv_wsplit_layout returns 1 where it applies (H % 8 == W % 8 == 0); the pre-split weights
  * must then be in MFMA fragment order (sgg_conv_split_weights_frag over the [taps][N][C] tensor: the HWOI transpose for the
  * forward, the HWIO kernel for dgrad) and w_split_layout = 1 is passed to sgg_conv2d_nhwc_fwd / _dgrad.  Layout 0 = planes. */
+/* (A/B switches read from the environment by the library: SGG_CONV_HALO=0 keeps sgg_conv2d_nhwc_wgrad on the per-tap
+ * kernels, SGG_ATTN_SPLIT=0 keeps sgg_attn_step_bwd on the one-workgroup-per-image kernel.) */
 int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);
 int sgg_conv_split_weights_frag(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
