@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
