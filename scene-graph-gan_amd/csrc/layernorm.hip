@@ -46,14 +46,12 @@ __global__ __launch_bounds__(256) void ln_stats_partial_kernel(const float* __re
     if (base >= N) break;
     f32x4 v[4];
     float s = 0.f;
-    int cnt = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = base + (threadIdx.x + 256 * j) * 4;
       if (e < N) {
         v[j] = *reinterpret_cast<const f32x4*>(yb + e);
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        cnt += 4;
       } else {
         v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
