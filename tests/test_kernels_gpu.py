@@ -362,6 +362,8 @@ HALO_CASES = [
     (2, 8, 8, 256, 256),
     (5, 40, 24, 32, 32),        # 75 blocks: several stages per workgroup, ragged last stage
     (3, 24, 40, 64, 64),
+    (1, 8, 8, 512, 512),        # 16 channel chunks, 4 n-tiles, one block: most XCD ranges are empty
+    (9, 8, 16, 64, 32),         # 18 blocks over 8 XCD ranges of 0..1 tiles (N = 32 tile: 4 blocks per workgroup)
 ]
 
 
