@@ -45,8 +45,8 @@ int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; ze
  * conv3_2) in precision 2 / 3: sgg_conv_wsplit_layout returns 1 where it applies (H % 8 == W % 8 == 0); the pre-split weights
  * must then be in MFMA fragment order (sgg_conv_split_weights_frag over the [taps][N][C] tensor: the HWOI transpose for the
  * forward, the HWIO kernel for dgrad) and w_split_layout = 1 is passed to sgg_conv2d_nhwc_fwd / _dgrad.  Layout 0 = planes. */
-/* (A/B switches read from the environment by the library: SGG_CONV_HALO=0 keeps sgg_conv2d_nhwc_wgrad on the per-tap
- * kernels, SGG_ATTN_SPLIT=0 keeps sgg_attn_step_bwd on the one-workgroup-per-image kernel.) */
+/* The library reads no environment variables and keeps no mutable global state: every kernel choice is a function of the
+ * arguments (w_split_layout here, `algo` of sgg_conv2d_nhwc_wgrad). */
 int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);
 int sgg_conv_split_weights_frag(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
@@ -59,10 +59,11 @@ int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int KH, in
 int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
                           const float* amax_dy, const float* amax_w, void* stream);
-/* Conv2DBackpropFilter: dw (HWIO) from x and dy */
+/* Conv2DBackpropFilter: dw (HWIO) from x and dy.  algo: 0 = automatic (halo-resident kernel where it applies), 1 = per-tap
+ * kernels only (A/B measurements). */
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int Hi, int Wi, int Cin, int Ho,
-                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                          int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int algo,
                           const float* amax_x, const float* amax_dy, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- tf.contrib.layers.layer_norm(activation_fn=tf.nn.elu) over (H,W,C) per sample ------------------------
@@ -106,6 +107,15 @@ int sgg_attn_ctx_gemm_dgrad(int B, int L, int LC, const float* dP, const float* 
                             void* workspace, size_t workspace_bytes, void* stream);
 int sgg_attn_ctx_gemm_wgrad(int B, int L, int LC, const float* ctx_flat, const float* dP, float* dw_ctx, int accumulate,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- tf.matmul(indices, W) with one-hot indices = embedding row gather ----------------------------------------
+ * discriminator_with_attention.py:86-87 on the real triples (float one-hots, train.py:173).
+ *   fwd  out[r, 0:E] = W[labels[r * label_stride], :]   (zero row for a label outside [0, V), as tf.one_hot)
+ *   bwd  dW[labels[r * label_stride], :] += dY[r, 0:E]  (rows sharing a label summed in row order: deterministic) */
+int sgg_embed_gather_fwd(const long long* labels, int label_stride, const float* W, int V, int E, float* out, int ldo, int R,
+                         void* stream);
+int sgg_embed_gather_bwd(const long long* labels, int label_stride, const float* dY, int lddy, float* dW, int V, int E, int R,
+                         void* stream);
 
 /* ---- attentionMechanism: score add -> softmax over L -> weighted sum of feature rows ------------------------
  * generator_with_attention.py:13-18 / discriminator_with_attention.py:13-18.

@@ -97,6 +97,17 @@ class RefKernels:
         r = A.t() @ Bm
         C.copy_(C + r if accumulate else r)
 
+    def attn_ctx_fwd(self, ctx_flat, W_ctx, bias, P):
+        P.copy_(ctx_flat @ W_ctx + bias)
+
+    def attn_ctx_dgrad(self, dP, W_ctx, dctx_flat, accumulate=True):
+        r = dP @ W_ctx.t()
+        dctx_flat.copy_(dctx_flat + r if accumulate else r)
+
+    def attn_ctx_wgrad(self, ctx_flat, dP, dW_ctx, accumulate=True):
+        r = ctx_flat.t() @ dP
+        dW_ctx.copy_(dW_ctx + r if accumulate else r)
+
     def attn_step_fwd(self, P, ec, ctx, alpha, z):
         B, L, C = ctx.shape
         R = ec.shape[1]
@@ -193,6 +204,13 @@ class RefKernels:
     # -- loss / optimiser / misc -----------------------------------------------------------------------
     def onehot(self, labels, out):
         out.copy_(torch.nn.functional.one_hot(labels, out.shape[-1]).to(out.dtype))
+
+    def embed_gather_fwd(self, labels, W, out):
+        """tf.matmul(one_hot(labels), W) (discriminator_with_attention.py:86-87 on train.py:173's one-hots)."""
+        out.copy_(torch.nn.functional.one_hot(labels, W.shape[0]).to(W.dtype) @ W)
+
+    def embed_gather_bwd(self, labels, dY, dW):
+        dW.add_(torch.nn.functional.one_hot(labels, dW.shape[0]).to(dW.dtype).t() @ dY)
 
     def interpolate(self, real, fake, alpha, out):
         B = real.shape[0]

@@ -27,10 +27,9 @@ __device__ __forceinline__ void split8_regs(const float (&x)[8], float scale, u3
     float a = x[2 * q], b = x[2 * q + 1];
     if constexpr (HALF) {
       a *= scale; b *= scale;
-      const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-      pl[0][q] = __builtin_bit_cast(unsigned, h);
-      const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
-      pl[1][q] = __builtin_bit_cast(unsigned, l);
+      unsigned hi, lo;
+      f16_split2(a, b, hi, lo);
+      pl[0][q] = hi; pl[1][q] = lo;
     } else {
 #pragma unroll
       for (int pp = 0; pp < P; ++pp) {
@@ -328,10 +327,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_tr_kernel(WgradParams p) {
       float a = v[2 * q], b = v[2 * q + 1];
       if constexpr (HALF) {
         a *= scale; b *= scale;
-        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-        pl[0][q] = __builtin_bit_cast(unsigned, h);
-        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
-        pl[1][q] = __builtin_bit_cast(unsigned, l);
+        unsigned hi, lo;
+      f16_split2(a, b, hi, lo);
+      pl[0][q] = hi; pl[1][q] = lo;
       } else {
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) {
@@ -603,17 +601,12 @@ extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, i
   return need;
 }
 
-// SGG_CONV_HALO=0 keeps the 3x3 stride-1 layers on the per-tap kernels (A/B measurements)
-static bool wgrad_halo_enabled() {
-  static const bool on = [] { const char* e = getenv("SGG_CONV_HALO"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,
-                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
+                                     int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int algo,
                                      const float* amax_x, const float* amax_dy, void* workspace, size_t workspace_bytes,
                                      void* stream) {
   SGG_CHECK_ARG(x && dy && dw, "sgg_conv2d_nhwc_wgrad: null pointer");
+  SGG_CHECK_ARG(algo == 0 || algo == 1, "sgg_conv2d_nhwc_wgrad: algo must be 0 (auto) or 1 (per-tap kernels only)");
   SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6,
                 "sgg_conv2d_nhwc_wgrad: precision must be 0, 2, 3 or 6");
   SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_dy), "sgg_conv2d_nhwc_wgrad: precision 2 needs the amax words");
@@ -631,7 +624,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   const long long nout = (long long)KH * KW * Cin * Cout;
   WgradHaloPlan hp;
   if ((precision == 2 || precision == 3) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho * stride && Wi == Wo * stride &&
-      wgrad_halo_enabled() && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp)) {
+      algo == 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp)) {
     // halo-resident kernel: the nine taps of a channel chunk from one LDS-resident patch (conv_wgrad_halo.hip)
     if (!workspace || workspace_bytes < hp.ws_bytes) {
       sgg_set_error("sgg_conv2d_nhwc_wgrad: workspace too small (%zu < %zu)", workspace_bytes, hp.ws_bytes);

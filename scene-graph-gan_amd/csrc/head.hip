@@ -546,8 +546,7 @@ extern "C" int sgg_attn_step_bwd(const float* ctx, const float* alpha, const flo
   SGG_CHECK_ARG(npass <= ATTN_MAX_PASS, "sgg_attn_step_bwd: at most %d rows per image (got %d)", ATTN_MAX_PASS, npass);
   hipStream_t st = (hipStream_t)stream;
   // full-size feature maps: split the locations of an image over several workgroups (see attn_step_bwd_ctx_kernel)
-  static const bool split_on = [] { const char* e = getenv("SGG_ATTN_SPLIT"); return !(e && e[0] == '0'); }();   // (A/B measurements)
-  const int ls = (split_on && B < 256 && L >= 64 && L <= 2048) ? (512 / B < L / 8 ? 512 / B : L / 8) : 1;
+  const int ls = (B < 256 && L >= 64 && L <= 2048) ? (512 / B < L / 8 ? 512 / B : L / 8) : 1;
   if (ls > 1) {
     if (alpha_dual) {
       SGG_CHECK_ARG(dz_dual && de_dual, "sgg_attn_step_bwd: dual pointers missing");

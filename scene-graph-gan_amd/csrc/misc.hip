@@ -167,6 +167,36 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) atomic_amax(amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+// tf.matmul(indices, W) for one-hot rows (discriminator_with_attention.py:86-87; real triples are one-hot floats, train.py:173):
+// the product degenerates to a row gather.  A label outside [0, V) gives a zero row, as tf.one_hot does.
+__global__ void embed_gather_fwd_kernel(const long long* __restrict__ labels, int lstride, const float* __restrict__ W, int V, int E,
+                                        float* __restrict__ out, int ldo) {
+  const int r = blockIdx.x;
+  const long long lab = labels[(size_t)r * lstride];
+  const bool ok = lab >= 0 && lab < V;
+  for (int i = threadIdx.x; i < E; i += blockDim.x) out[(size_t)r * ldo + i] = ok ? W[(size_t)lab * E + i] : 0.f;
+}
+
+// dW[labels[r], :] += dY[r, :].  Rows that share a label are summed in row order by the workgroup of the FIRST such row:
+// deterministic, no atomics (R is a few hundred at most).
+__global__ void embed_gather_bwd_kernel(const long long* __restrict__ labels, int lstride, const float* __restrict__ dY, int lddy,
+                                        float* __restrict__ dW, int V, int E, int R) {
+  extern __shared__ long long lab_s[];
+  for (int i = threadIdx.x; i < R; i += blockDim.x) lab_s[i] = labels[(size_t)i * lstride];
+  __syncthreads();
+  const int r = blockIdx.x;
+  const long long lab = lab_s[r];
+  if (lab < 0 || lab >= V) return;
+  for (int q = 0; q < r; ++q)
+    if (lab_s[q] == lab) return;            // an earlier row owns this label
+  for (int i = threadIdx.x; i < E; i += blockDim.x) {
+    float acc = dW[(size_t)lab * E + i];
+    for (int q = r; q < R; ++q)
+      if (lab_s[q] == lab) acc += dY[(size_t)q * lddy + i];
+    dW[(size_t)lab * E + i] = acc;
+  }
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------
 static inline int grid_for(long long n, int block) {
   long long g = (n + block - 1) / block;
@@ -203,6 +233,24 @@ extern "C" int sgg_onehot(const long long* labels, float* out, int rows, int V, 
   SGG_CHECK_ARG(labels && out && rows > 0 && V > 0, "sgg_onehot: bad argument");
   hipLaunchKernelGGL(onehot_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, labels, out, V);
   SGG_LAUNCH_CHECK("sgg_onehot");
+  return SGG_OK;
+}
+
+extern "C" int sgg_embed_gather_fwd(const long long* labels, int label_stride, const float* W, int V, int E, float* out, int ldo,
+                                    int R, void* stream) {
+  SGG_CHECK_ARG(labels && W && out && R > 0 && V > 0 && E > 0 && label_stride >= 1 && ldo >= E, "sgg_embed_gather_fwd: bad argument");
+  hipLaunchKernelGGL(embed_gather_fwd_kernel, dim3(R), dim3(128), 0, (hipStream_t)stream, labels, label_stride, W, V, E, out, ldo);
+  SGG_LAUNCH_CHECK("sgg_embed_gather_fwd");
+  return SGG_OK;
+}
+
+extern "C" int sgg_embed_gather_bwd(const long long* labels, int label_stride, const float* dY, int lddy, float* dW, int V, int E,
+                                    int R, void* stream) {
+  SGG_CHECK_ARG(labels && dY && dW && R > 0 && V > 0 && E > 0 && label_stride >= 1 && lddy >= E, "sgg_embed_gather_bwd: bad argument");
+  SGG_CHECK_ARG(R <= 4096, "sgg_embed_gather_bwd: at most 4096 rows per call (got %d)", R);
+  hipLaunchKernelGGL(embed_gather_bwd_kernel, dim3(R), dim3(128), (size_t)R * sizeof(long long), (hipStream_t)stream, labels,
+                     label_stride, dY, lddy, dW, V, E, R);
+  SGG_LAUNCH_CHECK("sgg_embed_gather_bwd");
   return SGG_OK;
 }
 

@@ -82,6 +82,17 @@ __device__ __forceinline__ int scale_exp_from_amax(float amax) {
   return e > 100 ? 100 : (e < -100 ? -100 : e);
 }
 
+// f16x3 mode: two floats (already scaled into fp16 range) -> packed hi and lo fp16 pieces, a = hi + lo up to 2^-23 relative.
+// Both conversions round to nearest even (v_cvt_pk_f16_f32): the split error is zero-mean, unlike a truncating split.
+typedef _Float16 sgg_h2 __attribute__((ext_vector_type(2)));
+typedef float sgg_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void f16_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const sgg_h2 h = __builtin_convertvector(sgg_f2{a, b}, sgg_h2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const sgg_h2 l = __builtin_convertvector(sgg_f2{a - (float)h[0], b - (float)h[1]}, sgg_h2);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 // XCD-aware bijective block remap (cdna_hip_programming.md T1): consecutive logical ids share an XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;

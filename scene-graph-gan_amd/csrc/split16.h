@@ -33,10 +33,9 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float s
     float a = x[2 * q], b = x[2 * q + 1];
     if constexpr (HALF) {
       a *= scale; b *= scale;
-      const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-      pl[0][q] = __builtin_bit_cast(unsigned, h);
-      const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
-      pl[1][q] = __builtin_bit_cast(unsigned, l);
+      unsigned hi, lo;
+      f16_split2(a, b, hi, lo);
+      pl[0][q] = hi; pl[1][q] = lo;
     } else {
 #pragma unroll
       for (int pp = 0; pp < P; ++pp) {

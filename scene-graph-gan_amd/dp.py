@@ -7,9 +7,10 @@ mean of the per-rank gradients equals the global-batch gradient.  Parameters and
 
 Collective: all-reduce(sum) of the live range of the flat gradient arena (params.py) in a few large buckets
 (xGMI is point-to-point, ring collectives are per-link bound: few, large messages), scaled by 1/world inside the
-fused Adam kernel.  Overlap (step.py): the critic-gradient all-reduce runs while the generator step's G-encoder
-forward executes (independent of the critic's weights); the generator-gradient all-reduce runs under the next
-critic step's D-encoder forward.
+fused Adam kernel.  Overlap (step.py): the Adam step of a network is deferred until its weights are next needed, and
+the network whose reduce is NOT in flight is issued first: the critic-gradient all-reduce runs under G's forward (of
+the generator step, or of the next critic update when critic_iters > 1), the generator-gradient all-reduce under the
+next critic step's D-encoder forward.  tests/test_dp_order.py pins that order with a recording reducer.
 """
 from __future__ import annotations
 

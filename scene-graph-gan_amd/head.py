@@ -99,13 +99,15 @@ class Head:
     def precompute(self, ctx):
         """P = ctx_flat @ W_ctx + b_att, once per feature map; also clears the dP / dctx accumulators."""
         K = self.K
-        K.gemm_nn(ctx.view(self.B, self.L * C), self.W_ctx, self.P, self.b_att)
+        K.attn_ctx_fwd(ctx.view(self.B, self.L * C), self.W_ctx, self.b_att, self.P)
         K.fill(self.dP, 0.0)
         K.fill(self.dctx, 0.0)
 
-    def forward(self, st, ctx, u):
+    def forward(self, st, ctx, u, labels=None, label_rows=None):
         """u: generator: noise [R, 512] (reused at t = 0,1,2, generator_with_attention.py:81,86);
         critic: list over planes of triples [R, 3, V] (float one-hot / logits / tangent direction).
+        labels int64 [n, 3] + label_rows (lo, hi): rows [lo, hi) of u[0] are the one-hots of `labels` (the real triples,
+        train.py:173) - their embedding product tf.matmul(indices, W) (discriminator_with_attention.py:87) is a row gather.
         Fills st.OUT [np, R, 3, Vout]."""
         K, np_, R, ind = self.K, st.np, st.R, self.in_dim
         K.spatial_mean_fwd(ctx, st.C[0][0], st.XH[0][0][:, ind:])       # plane 1 (tangent of c0 = h0) stays zero
@@ -116,7 +118,14 @@ class Head:
                 st.XH[t][0][:, C:ind].copy_(u)
             else:
                 for pl in range(np_):
-                    K.gemm_nn(u[pl][:, t, :], self.W_emb, st.XH[t][pl][:, C:ind])
+                    if labels is not None and pl == 0:
+                        lo, hi = label_rows
+                        for a, b in ((0, lo), (hi, R)):
+                            if b > a:
+                                K.gemm_nn(u[0][a:b, t, :], self.W_emb, st.XH[t][0][a:b, C:ind])
+                        K.embed_gather_fwd(labels[:, t], self.W_emb, st.XH[t][0][lo:hi, C:ind])
+                    else:
+                        K.gemm_nn(u[pl][:, t, :], self.W_emb, st.XH[t][pl][:, C:ind])
             K.gemm_nn(flat2(st.XH[t]), self.Kk, flat2(st.G[t]))
             K.lstm_fwd(st.G[t], st.C[t], self.ln, st.C[t + 1], st.XH[t + 1][:, :, ind:])
             K.gemm_nn(st.XH[t + 1][0][:, ind:], self.W_dec, st.OUT[0][:, t, :], self.b_dec)
@@ -136,9 +145,10 @@ class Head:
             K.gemm_tn(X[0][:R_w], dY[1][:R_w], dW, accumulate=True)
             K.gemm_tn(X[1][:R_w], dY[0][:R_w], dW, accumulate=True)
 
-    def backward(self, st, ctx, u, R_w):
+    def backward(self, st, ctx, u, R_w, labels=None, label_rows=None):
         """Backward of `forward` from st.dOUT. Rows [0, R_w) contribute to parameter / dP / dctx gradients (all
-        accumulated); every row gets its data cotangents (st.dXH[t][:, :, 512:in] = cotangent of u_t)."""
+        accumulated); every row gets its data cotangents (st.dXH[t][:, :, 512:in] = cotangent of u_t).
+        labels / label_rows as in forward: the embedding gradient of the one-hot rows is a row scatter-add."""
         K, np_, R, ind = self.K, st.np, st.R, self.in_dim
         pc = np_ - 1                                    # plane holding cotangents of real quantities
         assert R_w % self.B == 0 and (np_ == 1 or R_w == R)
@@ -155,7 +165,15 @@ class Head:
             self._wgrad(st.XH[t], st.dG, self.gKk, R_w)
             K.gemm_nt(flat2(st.dG), self.Kk, flat2(st.dXH[t]))
             if self.kind == "D" and R_w:
-                self._wgrad([x[:, t, :] for x in u], st.dXH[t][:, :, C:ind], self.gW_emb, R_w)
+                if labels is not None and np_ == 1:
+                    lo, hi = label_rows
+                    assert hi <= R_w
+                    for a, b in ((0, lo), (hi, R_w)):
+                        if b > a:
+                            K.gemm_tn(u[0][a:b, t, :], st.dXH[t][0][a:b, C:ind], self.gW_emb, accumulate=True)
+                    K.embed_gather_bwd(labels[:, t], st.dXH[t][0][lo:hi, C:ind], self.gW_emb)
+                else:
+                    self._wgrad([x[:, t, :] for x in u], st.dXH[t][:, :, C:ind], self.gW_emb, R_w)
             dz = st.dXH[t][:, :, :C]
             if R_w:
                 K.attn_step_bwd(ctx, st.AL[t][:, :R_w], dz[:, :R_w], st.dE[:, :R_w], self.dP, self.dctx, True)
@@ -173,6 +191,6 @@ class Head:
         K, B, L = self.K, self.B, self.L
         ctx_flat = ctx.view(B, L * C)
         K.colsum(self.dP, self.gb_att, True)
-        K.gemm_tn(ctx_flat, self.dP, self.gW_ctx, accumulate=True)
-        K.gemm_nt(self.dP, self.W_ctx, self.dctx.view(B, L * C), accumulate=True)
+        K.attn_ctx_wgrad(ctx_flat, self.dP, self.gW_ctx, accumulate=True)
+        K.attn_ctx_dgrad(self.dP, self.W_ctx, self.dctx.view(B, L * C), accumulate=True)
         return self.dctx

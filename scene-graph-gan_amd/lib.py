@@ -36,7 +36,7 @@ SIGNATURES = {
     "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
     "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
-    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _sz, _vp]),
+    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
     "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 4 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 3 + [_vp, _sz, _vp]),
@@ -56,6 +56,8 @@ SIGNATURES = {
     "sgg_colsum_workspace_bytes": (_sz, [_i, _i]),
     "sgg_colsum": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "sgg_onehot": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sgg_embed_gather_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "sgg_embed_gather_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sgg_interpolate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sgg_wgan_gp_loss_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sgg_wgan_gp_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
@@ -128,7 +130,7 @@ class HipKernels:
         self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
         self.conv_halo = os.environ.get("SGG_CONV_HALO", "1") != "0"
         assert self.conv_precision in (0, 2, 3, 6)
-        self._amax_scratch = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._amax_by_stream = {}
 
     def _timed(self, symbol, flops, fn):
         """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline leg)."""
@@ -206,7 +208,11 @@ class HipKernels:
         """precision 2 needs max|t| on the device; callers that track it pass `amax`, otherwise it is computed here."""
         if self.conv_precision != 2 or amax is not None or t is None:
             return amax
-        w = self._amax_scratch[slot:slot + 1]
+        sid = torch.cuda.current_stream(self.device).cuda_stream     # scratch words per stream, like workspace()
+        scratch = self._amax_by_stream.get(sid)
+        if scratch is None:
+            scratch = self._amax_by_stream[sid] = torch.zeros(8, dtype=torch.float32, device=self.device)
+        w = scratch[slot:slot + 1]
         self.fill(w, 0.0)
         self.absmax(t, w)
         return w
@@ -275,7 +281,8 @@ class HipKernels:
         if d[3] != 3:
             amax_x, amax_dy = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(dy, amax_dy, 1)
         self._check(self._timed("conv_wgrad(call: wgrad kernel + slab reduce)", flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
-            _p(x), _p(dy), _p(dw), *d, self.conv_precision, _p(amax_x), _p(amax_dy), _p(ws), ws.numel(), self._stream())),
+            _p(x), _p(dy), _p(dw), *d, self.conv_precision, 0 if self.conv_halo else 1, _p(amax_x), _p(amax_dy), _p(ws), ws.numel(),
+            self._stream())),
             "sgg_conv2d_nhwc_wgrad")
 
     def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None, tile_stats=None):
@@ -349,6 +356,34 @@ class HipKernels:
         assert K == K2 and tuple(C.shape) == (M, N)
         self._gemm(2, M, N, K, A, Bm, C, None, accumulate)
 
+    def attn_ctx_fwd(self, ctx_flat, W_ctx, bias, P):
+        """P[B,L] = ctx_flat[B,L*C] @ W_ctx[L*C,L] + bias: the step-invariant part of the attention perceptron."""
+        self._dev(ctx_flat, W_ctx, bias, P)
+        B, LC = ctx_flat.shape
+        L = P.shape[1]
+        assert ctx_flat.is_contiguous() and W_ctx.is_contiguous() and P.is_contiguous() and tuple(W_ctx.shape) == (LC, L)
+        ws = self.workspace(self.lib.sgg_gemm_workspace_bytes(B, L, LC))
+        self._check(self.lib.sgg_attn_ctx_gemm_fwd(B, L, LC, _p(ctx_flat), _p(W_ctx), _p(bias), _p(P), _p(ws), ws.numel(),
+                                                   self._stream()), "sgg_attn_ctx_gemm_fwd")
+
+    def attn_ctx_dgrad(self, dP, W_ctx, dctx_flat, accumulate=True):
+        self._dev(dP, W_ctx, dctx_flat)
+        B, L = dP.shape
+        LC = W_ctx.shape[0]
+        assert dP.is_contiguous() and W_ctx.is_contiguous() and dctx_flat.is_contiguous()
+        ws = self.workspace(self.lib.sgg_gemm_workspace_bytes(B, LC, L))
+        self._check(self.lib.sgg_attn_ctx_gemm_dgrad(B, L, LC, _p(dP), _p(W_ctx), _p(dctx_flat), int(accumulate), _p(ws), ws.numel(),
+                                                     self._stream()), "sgg_attn_ctx_gemm_dgrad")
+
+    def attn_ctx_wgrad(self, ctx_flat, dP, dW_ctx, accumulate=True):
+        self._dev(ctx_flat, dP, dW_ctx)
+        B, LC = ctx_flat.shape
+        L = dP.shape[1]
+        assert ctx_flat.is_contiguous() and dP.is_contiguous() and dW_ctx.is_contiguous()
+        ws = self.workspace(self.lib.sgg_gemm_workspace_bytes(LC, L, B))
+        self._check(self.lib.sgg_attn_ctx_gemm_wgrad(B, L, LC, _p(ctx_flat), _p(dP), _p(dW_ctx), int(accumulate), _p(ws), ws.numel(),
+                                                     self._stream()), "sgg_attn_ctx_gemm_wgrad")
+
     @staticmethod
     def _planes(t):
         """[np, R, W] (strided) -> (ptr_real, ptr_dual or None, ld)"""
@@ -421,6 +456,24 @@ class HipKernels:
         assert labels.dtype == torch.int64
         V = out.shape[-1]
         self._check(self.lib.sgg_onehot(_p(labels), _p(out), labels.numel(), V, self._stream()), "sgg_onehot")
+
+    def embed_gather_fwd(self, labels, W, out):
+        """labels: int64 [R] (strided) view; W [V,E]; out [R,E] view: out[r] = W[labels[r]] (tf.matmul(one_hot, W))."""
+        self._dev(labels, W, out)
+        assert labels.dtype == torch.int64 and labels.dim() == 1 and W.is_contiguous() and out.stride(1) == 1
+        V, E = W.shape
+        R = labels.shape[0]
+        self._check(self.lib.sgg_embed_gather_fwd(_p(labels), max(labels.stride(0), 1), _p(W), V, E, _p(out), _ld(out), R,
+                                                  self._stream()), "sgg_embed_gather_fwd")
+
+    def embed_gather_bwd(self, labels, dY, dW):
+        """dW[labels[r]] += dY[r] (deterministic)."""
+        self._dev(labels, dY, dW)
+        assert labels.dtype == torch.int64 and labels.dim() == 1 and dW.is_contiguous() and dY.stride(1) == 1
+        V, E = dW.shape
+        R = labels.shape[0]
+        self._check(self.lib.sgg_embed_gather_bwd(_p(labels), max(labels.stride(0), 1), _p(dY), _ld(dY), _p(dW), V, E, R,
+                                                  self._stream()), "sgg_embed_gather_bwd")
 
     def interpolate(self, real, fake, alpha, out):
         self._dev(real, fake, alpha, out)

@@ -136,21 +136,30 @@ class GanStep:
         = (disc_cost, wasserstein term, gradient penalty, mean D(fake)) as a device tensor."""
         K, B, V, D = self.K, self.B, self.V, self.D
         fake_rows, real_rows, hat_rows = self.TRI[:B], self.TRI[B:2 * B], self.TRI[2 * B:]
-        ctx = self._d_encoder_on_side_stream(images, zero_grads=True)    # independent of G's weights
-        self.G.finish_update()
-        gst, _ = self.generator_forward(images, noise)
+        # Data parallel: the network WITHOUT a gradient all-reduce in flight goes first, so that its encoder forward
+        # runs under the other network's collective before anything waits for it (critic_iters = 1: G's reduce from the
+        # last generator step hides under D's encoder; critic_iters > 1: D's reduce from the previous critic update
+        # hides under G's forward).  With a side stream the wait is enqueued there and never blocks the main stream.
+        if D.pending is None or self.side is not None:
+            ctx = self._d_encoder_on_side_stream(images, zero_grads=True)
+            self.G.finish_update()
+            gst, _ = self.generator_forward(images, noise)
+        else:
+            self.G.finish_update()
+            gst, _ = self.generator_forward(images, noise)
+            ctx = self._d_encoder_on_side_stream(images, zero_grads=True)
         self._join_side()
         fake_rows.copy_(gst.OUT[0])
         K.onehot(labels, real_rows)
         K.interpolate(real_rows, fake_rows, alpha, hat_rows)
         # ---- first-order pass on the 3B-row super-batch ------------------------------------------------
         st = D.head.state(1, 3 * B)
-        D.head.forward(st, ctx, [self.TRI])
+        D.head.forward(st, ctx, [self.TRI], labels, (B, 2 * B))
         inv = 1.0 / (B * T_STEPS)
         K.fill(st.dOUT[0][:B], inv)               # d mean(D(fake))
         K.fill(st.dOUT[0][B:2 * B], -inv)         # d -mean(D(real))
         K.fill(st.dOUT[0][2 * B:], 1.0)           # d sum(D(x_hat)) -> g
-        D.head.backward(st, ctx, [self.TRI], R_w=2 * B)
+        D.head.backward(st, ctx, [self.TRI], R_w=2 * B, labels=labels, label_rows=(B, 2 * B))
         ind = D.head.in_dim
         for t in range(T_STEPS):
             K.gemm_nt(st.dXH[t][0][2 * B:, FEAT_C:ind], D.head.W_emb, self.gbuf[:, t, :])
@@ -175,8 +184,14 @@ class GanStep:
         K, B, G, D = self.K, self.B, self.G, self.D
         G.finish_update()
         G.zero_grads()
-        ctx = self._d_encoder_on_side_stream(images, zero_grads=False)   # independent of G's forward
-        gst, gctx = self.generator_forward(images, noise)
+        if D.pending is None or self.side is not None:
+            ctx = self._d_encoder_on_side_stream(images, zero_grads=False)   # independent of G's forward
+            gst, gctx = self.generator_forward(images, noise)
+        else:
+            # the critic-gradient all-reduce launched at the end of critic_step runs under G's forward; only then does
+            # D.finish_update() wait for it
+            gst, gctx = self.generator_forward(images, noise)
+            ctx = self._d_encoder_on_side_stream(images, zero_grads=False)
         fake = gst.OUT[0]
         self._join_side()
         st = D.head.state(1, B, "g")

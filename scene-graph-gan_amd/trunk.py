@@ -42,7 +42,9 @@ class Trunk:
             # 3x3 stride-1 layers on 8-divisible grids: halo-resident kernel, weights pre-arranged as MFMA fragments
             # (re-derived in refresh_weights: the layout depends on the conv precision in force)
             lay["hin"], lay["win"] = h, w
-            lay["ws_layout"] = K.conv_wsplit_layout(k, s, h, w, cin, cout) if (cin != 3 and hasattr(K, "conv_wsplit_layout")) else 0
+            # forward and dgrad are asked separately: the kernels' channel conditions are not symmetric in (cin, cout)
+            lay["ws_layout"] = lay["ws_layout_bwd"] = 0
+            self._query_layouts(lay)
             if cin != 3 and getattr(K, "conv_precision", 0) and hasattr(K, "split_weights"):
                 lay["ws_fwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
                 lay["ws_bwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
@@ -69,6 +71,14 @@ class Trunk:
         self.amax = torch.zeros((3, 16), device=dev, dtype=torch.float32)
         self.refresh_weights()
 
+    def _query_layouts(self, lay):
+        K = self.K
+        if lay["cin"] != 3 and hasattr(K, "conv_wsplit_layout"):
+            k, s = lay["k"], lay["s"]
+            lay["ws_layout"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cin"], lay["cout"])
+            ho, wo = lay["out_shape"][1], lay["out_shape"][2]
+            lay["ws_layout_bwd"] = K.conv_wsplit_layout(k, s, ho, wo, lay["cout"], lay["cin"]) if s == 1 else 0
+
     def _f16(self):
         return getattr(self.K, "conv_precision", 0) == 2
 
@@ -85,9 +95,9 @@ class Trunk:
                 if self._f16():
                     self.K.absmax(lay["w"], self._am(2, j))
                 if lay["ws_fwd"] is not None and self.K.conv_precision:
-                    lay["ws_layout"] = self.K.conv_wsplit_layout(lay["k"], lay["s"], lay["hin"], lay["win"], lay["cin"], lay["cout"])
+                    self._query_layouts(lay)
                     self.K.split_weights(lay["w_fwd"], lay["ws_fwd"], self._am(2, j), lay["ws_layout"])
-                    self.K.split_weights(lay["w"], lay["ws_bwd"], self._am(2, j), lay["ws_layout"])
+                    self.K.split_weights(lay["w"], lay["ws_bwd"], self._am(2, j), lay["ws_layout_bwd"])
                     lay["ws_mode"] = self.K.conv_precision
 
     def forward(self, images):
@@ -144,7 +154,7 @@ class Trunk:
             dYp = self._dY[:numel].view(prev["out_shape"])
             ws = lay["ws_bwd"] if (lay["ws_bwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
             if ws is not None or f16:
-                K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout"] if ws is not None else 0)
+                K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"] if ws is not None else 0)
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])
             if f16:
