@@ -1,12 +1,20 @@
 """bench.py - triples/sec of the WGAN-GP "G+D step" (one critic update + one generator update on one minibatch,
 train.py:362-368 with CRITIC_ITERS = 1) on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--config {1,3,4}]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload = BASELINE.json configs[1]: batch 64 per GPU, 224x224 synthetic images, vocab 1000, length-3 triples
+Default workload = BASELINE.json configs[1]: batch 64 per GPU, 224x224 synthetic images, vocab 1000, length-3 triples
 (weak scaling: the global batch is 64*N, sharded by rows of one seeded global draw; the only exchange is the
-gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
+
+  value / ms_per_step   the timed region (default conv contraction mode, see DTYPE_NAME)
+  roofline              dominant convolution kernel against the MFMA peak (live HIP events around its launches)
+  roofline_hbm          the memory-bound kernels (LSTM gates, attention, attention product, LayerNorm, Adam) against HBM peak
+  native_f32            the same workload re-timed in the same run with native f32 MFMA arithmetic (mode 0)
+  parity                same-run checks: default mode vs native f32 (logits, tokens) and both vs the CPU oracle
+  cpu_baseline          the CPU oracle timed on this box's host cores (same run, N = 1 only)
+  rccl                  (N > 1) what the collective layer saw and how much of the all-reduce is exposed
 """
 from __future__ import annotations
 
@@ -23,14 +31,26 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip table: Peak FP32 (matrix)
-MFMA_BF16_PEAK_TFLOPS = 2500.0    # same table: Peak BF16 MFMA, dense
-MFMA_F16_PEAK_TFLOPS = 2500.0     # f16 MFMA runs at the bf16 rate (MI355X_MICROARCH.md, Matrix cores table)
-SUSTAINED_F16_MFMA_TFLOPS = 1635.0   # measured, random operands (see the roofline note below)
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # same table: Peak BF16 MFMA, dense (f16 MFMA runs at the bf16 rate)
+HBM_PEAK_GBPS = 8000.0            # same table: HBM3E
+SUSTAINED_F16_MFMA_TFLOPS = 1635.0   # measured, random operands (profiles/r01_ubench_mfma16_peak.log)
 DTYPE_NAME = {0: "f32 (native f32 MFMA)",
-              2: "f32 (conv operands scaled per tensor and split into 2 fp16 pieces = 22 significant bits, 3 fp16 MFMAs per "
-                 "product, f32 accumulate; error vs fp64 = native f32)",
-              6: "f32 (conv operands split into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate; error vs fp64 = native f32)",
+              2: "f32 (conv operands scaled per tensor and split into 2 fp16 pieces, round-to-nearest = 23 significant bits, "
+                 "3 fp16 MFMAs per product, f32 accumulate; native-f32 figure and parity in the same line)",
+              6: "f32 (conv operands split into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate)",
               3: "f32 storage, conv operands split into 2 bf16 pieces (3 bf16 MFMAs per product, f32 accumulate)"}
+# BASELINE.json configs[i] that fit one GPU: rows per GPU, image side, vocabulary
+CONFIGS = {1: (64, 224, 1000), 3: (64, 224, 70000), 4: (32, 448, 1000)}
+CONFIG_NOTE = {1: "1xMI355X, batch 64, 224x224, vocab 1000", 3: "Visual-Genome-scale vocab 70k", 4: "large image, batch 32, 448x448"}
+
+
+def workload_name(B, S, V, CI):
+    tail = "batch %d per GPU, %dx%d synthetic images, vocab %d, 3-token triples, %d critic update%s + 1 generator update per step " \
+           "(WGAN-GP lambda=10, TF-Adam)" % (B, S, S, V, CI, "" if CI == 1 else "s")
+    for i, cfg in CONFIGS.items():
+        if cfg == (B, S, V):
+            return "BASELINE.json configs[%d] (%s): %s" % (i, CONFIG_NOTE[i], tail)
+    return "custom (not a BASELINE.json config): " + tail
 
 
 def conv_flops_per_step(B, S):
@@ -67,23 +87,107 @@ def synth_inputs(B_global, S, V, n_draws, rank, world, device):
     return images, labels, noises, alphas
 
 
-def cpu_baseline(S, V, rows, threads, steps=2):
-    """The CPU oracle (restatement of the reference, oracle/sgg_oracle.py) timed on this box's host cores on a
-    bounded sample of the same workload: `rows` rows of the 64-row batch, `steps` full G+D steps (about 10-30 s)."""
+def summarise_timing(timing):
+    per = {}
+    for sym, fl, nb, e0, e1 in timing:
+        a = per.setdefault(sym, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += fl
+        a[2] += nb
+        a[3] += e0.elapsed_time(e1) * 1e-3
+    return per
+
+
+def conv_roofline(per, precision, dt):
+    """Roofline record of the dominant convolution kernel (largest summed duration among the forward/dgrad kernels)."""
+    conv = [s for s in per if s.startswith(("conv_gather", "conv_halo", "conv_s2"))]
+    if not conv:
+        return None
+    dom = max(conv, key=lambda s: per[s][3])
+    n, fl, _, sec = per[dom]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom)
+    nprod = {0: 1, 2: 3, 3: 3, 6: 6}[precision]
+    peak = MFMA_BF16_PEAK_TFLOPS / nprod if precision else MFMA_F32_PEAK_TFLOPS
+    note = ("dense %s MFMA peak %.0f TFLOP/s / %d MFMA products per algorithmic f32 product"
+            % ("f16" if precision == 2 else "bf16", MFMA_BF16_PEAK_TFLOPS, nprod) if precision else "f32 matrix peak")
+    r = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
+         "frac": fl / sec / 1e12 / peak, "traffic": traffic, "mfma_tflops_issued": nprod * fl / sec / 1e12,
+         "vs_native_f32_mfma_peak": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "launches": n, "avg_launch_ms": 1e3 * sec / n,
+         "flop_per_launch": fl / n, "share_of_step_time": sec / dt}
+    if precision in (2, 3):
+        # a register-only loop of v_mfma_f32_32x32x16_f16 on random operands sustains 1.56-1.71 PFLOP/s: the chip clocks down
+        # under matrix load (2.46 PFLOP/s only with all-zero operands) -> / 3 products
+        r["sustained_mfma_peak_measured"] = SUSTAINED_F16_MFMA_TFLOPS / nprod
+        r["frac_of_sustained"] = fl / sec / 1e12 / (SUSTAINED_F16_MFMA_TFLOPS / nprod)
+    return r
+
+
+def hbm_rooflines(per, steps):
+    """The memory-bound calls against the HBM peak: algorithmic bytes (sgg_amd/lib.py) / event-measured time."""
+    out = []
+    for sym, (n, _, nb, sec) in sorted(per.items(), key=lambda kv: -kv[1][3]):
+        if nb <= 0 or sec <= 0:
+            continue
+        gbps = nb / sec / 1e9
+        out.append({"kernel": sym, "launches_per_step": round(n / steps, 2), "bytes": nb / n, "avg_us": 1e6 * sec / n,
+                    "GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS, "ms_per_step": 1e3 * sec / steps})
+    return out
+
+
+def parity_and_cpu_baseline(K, S, V, rows, threads, precisions):
+    """One full G+D step of the CPU oracle (oracle/sgg_oracle.py, the restatement of the reference) on `rows` rows of the
+    workload, timed on this box's host cores = cpu_baseline; the same step on the GPU (same weights, inputs, noise) in
+    each of `precisions` = the same-run parity record.  Tolerances as in tests/test_step_gpu.py."""
     from oracle import sgg_oracle as O
+    from sgg_amd.step import GanStep
     torch.set_num_threads(threads)
     gp, dp = O.init_params("G", V, S), O.init_params("D", V, S)
+    gp0, dp0 = {k: v.clone() for k, v in gp.items()}, {k: v.clone() for k, v in dp.items()}
     images, labels, onehot = O.synth_batch(rows, S, V)
+    noise0, noise1, alpha = O.synth_noise(rows, 0), O.synth_noise(rows, 1), O.synth_alpha(rows, 0)
     d_adam, g_adam = O.new_adam_state(dp), O.new_adam_state(gp)
     t0 = time.time()
-    for k in range(steps):
-        O.d_step(gp, dp, d_adam, k + 1, images, onehot, O.synth_noise(rows, 2 * k), O.synth_alpha(rows, k))
-        O.g_step(gp, dp, g_adam, k + 1, images, O.synth_noise(rows, 2 * k + 1))
+    cost, aux, _ = O.d_step(gp, dp, d_adam, 1, images, onehot, noise0, alpha)
+    gcost, gaux, _ = O.g_step(gp, dp, g_adam, 1, images, noise1)
     dt = time.time() - t0
-    return {"value": rows * steps / dt, "unit": "triples/sec", "cores": threads, "kind": "port",
-            "sample": "%d G+D steps on %d of the 64 rows of configs[1] (%dx%d, vocab %d), oracle/sgg_oracle.py fp32 "
-                      "(PyTorch CPU restatement of the reference; the reference itself cannot run here), "
-                      "%d torch threads, %.1f s" % (steps, rows, S, S, V, threads, dt)}
+    cpu = {"value": rows / dt, "unit": "triples/sec", "cores": threads, "kind": "port",
+           "sample": "1 full G+D step on %d rows of the workload (%dx%d, vocab %d), oracle/sgg_oracle.py fp32 (PyTorch CPU "
+                     "restatement of the reference; the reference itself cannot run here), %d torch threads, %.1f s"
+                     % (rows, S, S, V, threads, dt)}
+    ref_toks = O.argmax_tokens(gaux["fake"])
+    margin = O.top2_margin(gaux["fake"])
+    tol = lambda ref: 1e-4 + 1e-4 * abs(float(ref))
+    dev = K.device
+    old = K.conv_precision
+    par = {"rows": rows, "tolerance": "losses and logits |d| <= 1e-4 + 1e-4*|ref|, tokens exact", "top2_logit_margin": margin}
+    try:
+        for prec in precisions:
+            K.conv_precision = prec
+            gs = GanStep(K, V, S, rows, lam=10.0, g_state=gp0, d_state=dp0)
+            dl = gs.critic_step(images.to(dev), labels.to(dev), noise0.to(dev), alpha.reshape(rows).to(dev)).cpu()
+            logit_err = float((gs.G.head.state(1, rows).OUT[0].cpu() - aux["fake"]).abs().max())
+            # the generator step is compared on identical critic weights (the first Adam step is sign-like: gradient
+            # elements at fp32 noise level move by +-lr in either implementation; DESIGN.md, Parity)
+            gs.D.arena.load_state_dict(dp)
+            gs.D.trunk.refresh_weights()
+            gl = gs.generator_step(images.to(dev), noise1.to(dev)).cpu()
+            toks = gs.argmax_tokens(gs.G.head.state(1, rows).OUT[0]).cpu()
+            rec = {"disc_cost": float(dl[0]), "disc_cost_oracle": float(cost), "gp": float(dl[2]), "gp_oracle": float(aux["gp"]),
+                   "gen_cost": -float(gl[3]), "gen_cost_oracle": float(gcost),
+                   "loss_err_vs_oracle": max(abs(float(dl[0]) - float(cost)), abs(-float(gl[3]) - float(gcost))),
+                   "max_logit_err_vs_oracle": logit_err, "max_abs_logit_oracle": float(aux["fake"].abs().max()),
+                   "tokens_equal_oracle": bool(torch.equal(toks, ref_toks))}
+            rec["ok"] = bool(abs(float(dl[0]) - float(cost)) <= tol(cost) and abs(-float(gl[3]) - float(gcost)) <= tol(gcost)
+                             and logit_err <= tol(aux["fake"].abs().max()) and rec["tokens_equal_oracle"])
+            par["precision%d_vs_oracle" % prec] = rec
+            del gs
+            torch.cuda.empty_cache()
+    finally:
+        K.conv_precision = old
+    return cpu, par
 
 
 def main():
@@ -91,17 +195,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="rows per GPU (configs[1]: 64)")
-    ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--vocab", type=int, default=1000)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i] preset (default 1)")
+    ap.add_argument("--batch", type=int, default=None, help="rows per GPU (overrides the preset)")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--vocab", type=int, default=None)
     ap.add_argument("--critic-iters", type=int, default=1)
-    ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the cpu_baseline / oracle-parity step (0 = skip; default: the "
+                                                               "whole per-GPU batch up to 224x224, 16 rows at 448x448)")
+    ap.add_argument("--f32-steps", type=int, default=3, help="steps of the native-f32 leg (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="add per-layer conv timings to the JSON line")
     ap.add_argument("--overlap-streams", action="store_true", help="run the two encoders' forwards on two HIP streams (+3 %%)")
     ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 2, 3, 6],
-                    help="conv contraction: 2 = scaled fp16 pieces, 3 products (default, f32-equivalent error), 6 = bf16 pieces, "
-                         "6 products (f32-equivalent), 0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance)")
+                    help="conv contraction: 2 = scaled fp16 pieces, 3 products (default), 6 = bf16 pieces, 6 products, "
+                         "0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance)")
     args = ap.parse_args()
 
     import sgg_amd  # noqa: F401
@@ -118,12 +225,17 @@ def main():
     K = HipKernels(dev)
     if args.conv_precision is not None:
         K.conv_precision = args.conv_precision
-    B, S, V, CI = args.batch, args.size, args.vocab, args.critic_iters
+    B0, S0, V0 = CONFIGS[args.config]
+    B = args.batch if args.batch is not None else B0
+    S = args.size if args.size is not None else S0
+    V = args.vocab if args.vocab is not None else V0
+    CI = args.critic_iters
     reducer = dpmod.GradReducer() if world > 1 else None
     gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer,
                  overlap_streams=args.overlap_streams)
+    extra = (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0)
     total_steps = args.warmup + args.steps
-    images, labels, noises, alphas = synth_inputs(B * world, S, V, total_steps * (CI + 1), rank, world, dev)
+    images, labels, noises, alphas = synth_inputs(B * world, S, V, (total_steps + extra) * (CI + 1), rank, world, dev)
 
     def one_step(k):
         base = k * (CI + 1)
@@ -137,86 +249,115 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(k0, n, with_events):
+        """n steps bracketed by barrier + synchronize on both sides; max over ranks."""
+        barrier()
+        K.timing = [] if with_events else None
+        t0 = time.perf_counter()
+        for k in range(k0, k0 + n):
+            one_step(k)
+        gs.flush()
+        barrier()
+        dt = time.perf_counter() - t0
+        timing, K.timing = K.timing, None
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, timing
+
     for k in range(args.warmup):
         one_step(k)
     gs.flush()
-    barrier()
-    if not args.no_kernel_timing:
-        K.timing = []
-    t0 = time.perf_counter()
-    for k in range(args.warmup, total_steps):
-        one_step(k)
-    gs.flush()
-    barrier()
-    dt = time.perf_counter() - t0
-    timing, K.timing = K.timing, None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, timing = timed(args.warmup, args.steps, not args.no_kernel_timing)
     d_losses, g_losses = gs.d_losses.cpu().tolist(), gs.g_losses.cpu().tolist()
+    next_k = total_steps
 
+    out = None
     if rank == 0:
         value = B * world * args.steps / dt
         out = {
             "metric": "triples/sec (G+D step)", "value": value, "unit": "triples/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NAME[K.conv_precision], "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch %d per GPU, %dx%d synthetic images, vocab %d, 3-token "
-                                   "triples, 1 critic update + 1 generator update per step (WGAN-GP lambda=10, TF-Adam)"
-                                   % (B, S, S, V), "global_batch": B * world, "critic_iters": CI,
-                       "parallelism": "dp%d" % world},
+            "config": {"workload": workload_name(B, S, V, CI), "global_batch": B * world, "critic_iters": CI,
+                       "parallelism": "dp%d" % world, "conv_precision_mode": K.conv_precision},
             "losses": {"disc_cost": d_losses[0], "gp": d_losses[2], "gen_cost": -g_losses[3]},
         }
         flops_step = conv_flops_per_step(B, S) * (CI + 1) / 2.0 if CI == 1 else None
         if flops_step:
             out["conv_tflops_whole_step_per_gpu"] = flops_step * args.steps / dt / 1e12
         if timing:
-            per = {}
-            for sym, fl, e0, e1 in timing:
-                a = per.setdefault(sym, [0, 0.0, 0.0])
-                a[0] += 1
-                a[1] += fl
-                a[2] += e0.elapsed_time(e1) * 1e-3
-            dom = max((s for s in per if s.startswith(("conv_gather", "conv_halo"))), key=lambda s: per[s][2])
-            n, fl, sec = per[dom]
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom)
-            nprod = {0: 1, 2: 3, 3: 3, 6: 6}[K.conv_precision]
-            peak = MFMA_BF16_PEAK_TFLOPS / nprod if K.conv_precision else MFMA_F32_PEAK_TFLOPS
-            note = ("dense %s MFMA peak %.0f TFLOP/s / %d MFMA products per algorithmic f32 product"
-                    % ("f16" if K.conv_precision == 2 else "bf16", MFMA_BF16_PEAK_TFLOPS, nprod)
-                    if K.conv_precision else "f32 matrix peak")
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": peak, "peak_note": note,
-                               "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic,
-                               "mfma_tflops_issued": nprod * fl / sec / 1e12, "vs_native_f32_mfma_peak": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                               "launches": n, "avg_launch_ms": 1e3 * sec / n, "flop_per_launch": fl / n,
-                               "share_of_step_time": sec / dt}
-            if K.conv_precision in (2, 3):
-                # scripts/ubench/mfma16_peak.hip (profiles/r01_ubench_mfma16_peak.log): a register-only loop of
-                # v_mfma_f32_32x32x16_f16 on random operands sustains 1.56-1.71 PFLOP/s (the chip clocks down to 1.5-1.7 GHz
-                # under matrix load; 2.46 PFLOP/s only with all-zero operands) -> / 3 products
-                out["roofline"]["sustained_mfma_peak_measured"] = SUSTAINED_F16_MFMA_TFLOPS / nprod
-                out["roofline"]["frac_of_sustained"] = fl / sec / 1e12 / (SUSTAINED_F16_MFMA_TFLOPS / nprod)
-            out["kernel_time_s"] = {s: round(v[2], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][2])}
-            out["kernel_tflops"] = {s: round(v[1] / v[2] / 1e12, 2) for s, v in per.items() if v[2] > 0}
+            per = summarise_timing(timing)
+            out["roofline"] = conv_roofline(per, K.conv_precision, dt)
+            out["roofline_hbm"] = hbm_rooflines(per, args.steps)
+            out["kernel_time_s"] = {s: round(v[3], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][3])}
+            out["kernel_tflops"] = {s: round(v[1] / v[3] / 1e12, 2) for s, v in per.items() if v[3] > 0 and v[1] > 0}
             if args.per_shape:     # per (kernel, FLOPs per launch) = per layer and direction
                 shp = {}
-                for sym, fl, e0, e1 in timing:
+                for sym, fl, nb, e0, e1 in timing:
+                    if fl <= 0:
+                        continue
                     a = shp.setdefault("%s @ %.1f GF" % (sym, fl / 1e9), [0, 0.0])
                     a[0] += 1
                     a[1] += e0.elapsed_time(e1) * 1e-3
                 out["per_shape"] = {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1] / args.steps, 3),
                                         "tflops": round(float(k.split("@")[1].split()[0]) * 1e9 * v[0] / v[1] / 1e12, 1)}
                                     for k, v in sorted(shp.items(), key=lambda kv: -kv[1][1])}
-        if world == 1 and args.cpu_rows > 0:
+
+    # ---- N > 1: what RCCL saw, and how much of the gradient all-reduce is exposed (same ranks, reducer off) --------------
+    if world > 1:
+        import torch.distributed as dist
+        gs.reducer = None
+        one_step(next_k)
+        dt_off, _ = timed(next_k + 1, 3, False)
+        next_k += 4
+        gs.reducer = reducer
+        if rank == 0:
+            ms_on, ms_off = 1e3 * dt / args.steps, 1e3 * dt_off / 3
+            out["rccl"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "bucket_bytes": reducer.bucket_elems * 4,
+                           "allreduce_bytes_per_step": 4 * (gs.G.arena.live_numel + CI * gs.D.arena.live_numel),
+                           "ms_per_step_without_allreduce": ms_off, "allreduce_ms_exposed": ms_on - ms_off}
+
+    # ---- the same workload in native f32 MFMA arithmetic, same run (the reference arithmetic is IEEE fp32) -----------------
+    if K.conv_precision != 0 and args.f32_steps > 0:
+        main_prec = K.conv_precision
+        st, _ = gs.generator_forward(images, noises[0])
+        logits_main = st.OUT[0].clone()
+        toks_main = gs.argmax_tokens(logits_main).clone()
+        K.conv_precision = 0
+        gs.G.trunk.refresh_weights()
+        gs.D.trunk.refresh_weights()
+        st, _ = gs.generator_forward(images, noises[0])
+        logits_f32 = st.OUT[0].clone()
+        toks_f32 = gs.argmax_tokens(logits_f32).clone()
+        one_step(next_k)
+        dt32, timing32 = timed(next_k + 1, args.f32_steps, not args.no_kernel_timing)
+        K.conv_precision = main_prec
+        gs.G.trunk.refresh_weights()
+        gs.D.trunk.refresh_weights()
+        if rank == 0:
+            out["native_f32"] = {"value": B * world * args.f32_steps / dt32, "unit": "triples/sec", "steps": args.f32_steps,
+                                 "ms_per_step": 1e3 * dt32 / args.f32_steps, "dtype": DTYPE_NAME[0]}
+            if timing32:
+                out["native_f32"]["roofline"] = conv_roofline(summarise_timing(timing32), 0, dt32)
+            from oracle import sgg_oracle as O
+            out["parity"] = {"mode%d_vs_native_f32" % main_prec: {
+                "max_logit_err": float((logits_main - logits_f32).abs().max()), "max_abs_logit": float(logits_f32.abs().max()),
+                "tokens_equal": bool(torch.equal(toks_main, toks_f32)), "top2_logit_margin": O.top2_margin(logits_f32.cpu()),
+                "on": "generator logits [%d,3,%d] of the timed workload after the timed steps, same weights" % (B, V)}}
+
+    if rank == 0:
+        rows = args.cpu_rows if args.cpu_rows is not None else (B if S <= 224 else min(B, 16))
+        if world == 1 and rows > 0:
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncpu = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(S, V, args.cpu_rows, min(ncpu, 16))   # a 1-GPU box grants 16 host cores
+            precs = sorted({K.conv_precision, 0})
+            cpu, par = parity_and_cpu_baseline(K, S, V, rows, min(ncpu, 16), precs)   # a 1-GPU box grants 16 host cores
+            out["cpu_baseline"] = cpu
+            out.setdefault("parity", {}).update(par)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

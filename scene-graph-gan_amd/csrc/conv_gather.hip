@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_gather3_kernel(G
 // operand split into P bf16 pieces x = x0 + x1 (+ x2) at the LDS-write and the cross terms accumulated in f32:
 //   P = 2 (3 products: x0w0 + x0w1 + x1w0):  drops terms of relative size 2^-17: logits err 2.0e-5 vs fp64
 //   P = 3 (6 products: + x1w1 + x0w2 + x2w0): drops terms of relative size 2^-25: logits err 1.9e-6 vs fp64,
-//          the same as the native f32 MFMA path (2.7e-6)   [tests/test_split_bf16_numerics.py, 8x64x64 config]
+//          the same as the native f32 MFMA path (2.7e-6)   [tests/test_split_numerics.py: CPU emulation of the piece arithmetic]
 // bf16 x bf16 products are exact in f32, the accumulator is f32, so only the dropped cross terms differ from f32.
 // Same skeleton as conv_gather3_kernel (buffer-load gather, scalar tap walk, register prefetch, one LDS buffer);
 // LDS planes are [row][32 k] bf16 (64 B rows) with the 16-B chunk index XOR-swizzled by (row >> 2) & 3, which makes

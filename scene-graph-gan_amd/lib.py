@@ -132,15 +132,16 @@ class HipKernels:
         assert self.conv_precision in (0, 2, 3, 6)
         self._amax_by_stream = {}
 
-    def _timed(self, symbol, flops, fn):
-        """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline leg)."""
+    def _timed(self, symbol, flops, fn, nbytes=0.0):
+        """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline legs).
+        flops / nbytes: ALGORITHMIC work of the call (MFMA-bound convs: flops; HBM-bound kernels: bytes)."""
         if self.timing is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(self.device))
         r = fn()
         e1.record(torch.cuda.current_stream(self.device))
-        self.timing.append((symbol, flops, e0, e1))
+        self.timing.append((symbol, flops, nbytes, e0, e1))
         return r
 
     def gather_symbol(self, n_out, presplit=False):
@@ -292,18 +293,21 @@ class HipKernels:
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
         ws = self.workspace(need)
         nts = 0 if tile_stats is None else tile_stats.shape[1]
-        self._check(self.lib.sgg_layernorm_hwc_elu_fwd(_p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), _p(tile_stats), nts,
-                                                       B, H * W, C, _p(ws),
-                                                       ws.numel(), self._stream()), "sgg_layernorm_hwc_elu_fwd")
+        # algorithmic bytes: read y (twice without epilogue statistics: statistics pass + apply pass), write a
+        nb = 4.0 * y.numel() * (2 if nts else 3)
+        self._check(self._timed("ln_elu_fwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_fwd(
+            _p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), _p(tile_stats), nts, B, H * W, C, _p(ws), ws.numel(),
+            self._stream()), nb), "sgg_layernorm_hwc_elu_fwd")
 
     def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None):
         self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out)
         B, H, W, C = y.shape
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
         ws = self.workspace(need)
-        self._check(self.lib.sgg_layernorm_hwc_elu_bwd(_p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma),
-                                                       _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C, _p(ws), ws.numel(),
-                                                       self._stream()), "sgg_layernorm_hwc_elu_bwd")
+        # algorithmic bytes: the reduction pass reads y and da, the apply pass reads them again and writes dy
+        self._check(self._timed("ln_elu_bwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_bwd(
+            _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma), _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C,
+            _p(ws), ws.numel(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")
 
     # -- heads -----------------------------------------------------------------------------------------
     def spatial_mean_fwd(self, ctx, out_c, out_h):
@@ -363,8 +367,9 @@ class HipKernels:
         L = P.shape[1]
         assert ctx_flat.is_contiguous() and W_ctx.is_contiguous() and P.is_contiguous() and tuple(W_ctx.shape) == (LC, L)
         ws = self.workspace(self.lib.sgg_gemm_workspace_bytes(B, L, LC))
-        self._check(self.lib.sgg_attn_ctx_gemm_fwd(B, L, LC, _p(ctx_flat), _p(W_ctx), _p(bias), _p(P), _p(ws), ws.numel(),
-                                                   self._stream()), "sgg_attn_ctx_gemm_fwd")
+        nb = 4.0 * (LC * L + B * LC + B * L)       # W_ctx streamed once + ctx + P
+        self._check(self._timed("attn_ctx_gemm_fwd(call: split-K gemm + reduce)", 2.0 * B * L * LC, lambda: self.lib.sgg_attn_ctx_gemm_fwd(
+            B, L, LC, _p(ctx_flat), _p(W_ctx), _p(bias), _p(P), _p(ws), ws.numel(), self._stream()), nb), "sgg_attn_ctx_gemm_fwd")
 
     def attn_ctx_dgrad(self, dP, W_ctx, dctx_flat, accumulate=True):
         self._dev(dP, W_ctx, dctx_flat)
@@ -372,8 +377,10 @@ class HipKernels:
         LC = W_ctx.shape[0]
         assert dP.is_contiguous() and W_ctx.is_contiguous() and dctx_flat.is_contiguous()
         ws = self.workspace(self.lib.sgg_gemm_workspace_bytes(B, LC, L))
-        self._check(self.lib.sgg_attn_ctx_gemm_dgrad(B, L, LC, _p(dP), _p(W_ctx), _p(dctx_flat), int(accumulate), _p(ws), ws.numel(),
-                                                     self._stream()), "sgg_attn_ctx_gemm_dgrad")
+        nb = 4.0 * (LC * L + B * L + B * LC * (2 if accumulate else 1))
+        self._check(self._timed("attn_ctx_gemm_dgrad(call)", 2.0 * B * L * LC, lambda: self.lib.sgg_attn_ctx_gemm_dgrad(
+            B, L, LC, _p(dP), _p(W_ctx), _p(dctx_flat), int(accumulate), _p(ws), ws.numel(), self._stream()), nb),
+            "sgg_attn_ctx_gemm_dgrad")
 
     def attn_ctx_wgrad(self, ctx_flat, dP, dW_ctx, accumulate=True):
         self._dev(ctx_flat, dP, dW_ctx)
@@ -381,8 +388,10 @@ class HipKernels:
         L = dP.shape[1]
         assert ctx_flat.is_contiguous() and dP.is_contiguous() and dW_ctx.is_contiguous()
         ws = self.workspace(self.lib.sgg_gemm_workspace_bytes(LC, L, B))
-        self._check(self.lib.sgg_attn_ctx_gemm_wgrad(B, L, LC, _p(ctx_flat), _p(dP), _p(dW_ctx), int(accumulate), _p(ws), ws.numel(),
-                                                     self._stream()), "sgg_attn_ctx_gemm_wgrad")
+        nb = 4.0 * (LC * L * (2 if accumulate else 1) + B * L + B * LC)
+        self._check(self._timed("attn_ctx_gemm_wgrad(call)", 2.0 * B * L * LC, lambda: self.lib.sgg_attn_ctx_gemm_wgrad(
+            B, L, LC, _p(ctx_flat), _p(dP), _p(dW_ctx), int(accumulate), _p(ws), ws.numel(), self._stream()), nb),
+            "sgg_attn_ctx_gemm_wgrad")
 
     @staticmethod
     def _planes(t):
@@ -402,8 +411,10 @@ class HipKernels:
         ar, ad, lda = self._planes(alpha)
         zr, zd, ldz = self._planes(z)
         assert lda == L
-        self._check(self.lib.sgg_attn_step_fwd(_p(P), er, ed, lde, _p(ctx), ar, ad, zr, zd, ldz, R, B, L, C, self._stream()),
-                    "sgg_attn_step_fwd")
+        np_ = ec.shape[0]
+        nb = 4.0 * (B * L * C + B * L + np_ * R * (2 * L + C))     # feature map once per image + P + ec, alpha, z
+        self._check(self._timed("attn_step_fwd_kernel<%s>" % ("Dual" if np_ == 2 else "float"), 0.0, lambda: self.lib.sgg_attn_step_fwd(
+            _p(P), er, ed, lde, _p(ctx), ar, ad, zr, zd, ldz, R, B, L, C, self._stream()), nb), "sgg_attn_step_fwd")
 
     def attn_step_bwd(self, ctx, alpha, dz, de, dP, dctx, accumulate):
         self._dev(ctx, alpha, dz, de, dP, dctx)
@@ -413,8 +424,11 @@ class HipKernels:
         zr, zd, ldz = self._planes(dz)
         er, ed, lde = self._planes(de)
         assert lda == L and lde == L
-        self._check(self.lib.sgg_attn_step_bwd(_p(ctx), ar, ad, zr, zd, ldz, er, ed, _p(dP), _p(dctx), R, B, L, C, int(accumulate),
-                                               self._stream()), "sgg_attn_step_bwd")
+        np_ = alpha.shape[0]
+        nb = 4.0 * (B * L * C * (3 if accumulate else 2) + B * L * 2 + np_ * R * (2 * L + C))   # ctx read, dctx read+write
+        self._check(self._timed("attn_step_bwd(call)<%s>" % ("Dual" if np_ == 2 else "float"), 0.0, lambda: self.lib.sgg_attn_step_bwd(
+            _p(ctx), ar, ad, zr, zd, ldz, er, ed, _p(dP), _p(dctx), R, B, L, C, int(accumulate), self._stream()), nb),
+            "sgg_attn_step_bwd")
 
     def lstm_fwd(self, gates, c_prev, ln_params, c_new, h_new):
         """gates [np,R,2048], c_prev/c_new [np,R,512] contiguous, h_new [np,R,512] view, ln_params [10,512]."""
@@ -425,8 +439,10 @@ class HipKernels:
         nr, nd, ldn = self._planes(c_new)
         hr, hd, ldh = self._planes(h_new)
         assert ldg == 2048 and ldc == 512 and ldn == 512
-        self._check(self.lib.sgg_lnlstm_gates_fwd(gr, gd, cr, cd, _p(ln_params), nr, nd, hr, hd, ldh, R, self._stream()),
-                    "sgg_lnlstm_gates_fwd")
+        np_ = gates.shape[0]
+        nb = 4.0 * (np_ * R * (2048 + 512 + 1024) + 10 * 512)     # gates + c in, c', h' out (+ the LN vectors)
+        self._check(self._timed("lnlstm_gates_fwd_kernel<%s>" % ("Dual" if np_ == 2 else "float"), 0.0, lambda: self.lib.sgg_lnlstm_gates_fwd(
+            gr, gd, cr, cd, _p(ln_params), nr, nd, hr, hd, ldh, R, self._stream()), nb), "sgg_lnlstm_gates_fwd")
 
     def lstm_bwd(self, gates, c_prev, ln_params, dh, dc_new, dgates, dc_prev, pgrad):
         """dh [np,R,512] view; dc_new [np,R,512] or None; outputs dgates [np,R,2048], dc_prev [np,R,512], pgrad [R,10,512]."""
@@ -439,8 +455,11 @@ class HipKernels:
         dgr, dgd, lddg = self._planes(dgates)
         dpr, dpd, lddp = self._planes(dc_prev)
         assert ldg == 2048 and ldc == 512 and lddg == 2048 and lddp == 512 and (dc_new is None or ldn == 512)
-        self._check(self.lib.sgg_lnlstm_gates_bwd(gr, gd, cr, cd, _p(ln_params), hr, hd, ldh, nr, nd, dgr, dgd, dpr, dpd,
-                                                  _p(pgrad), R, self._stream()), "sgg_lnlstm_gates_bwd")
+        np_ = gates.shape[0]
+        nb = 4.0 * (np_ * R * (2048 + 512 + 512 + (512 if dc_new is not None else 0) + 2048 + 512) + R * 5120 + 5120)
+        self._check(self._timed("lnlstm_gates_bwd_kernel<%s>" % ("Dual" if np_ == 2 else "float"), 0.0, lambda: self.lib.sgg_lnlstm_gates_bwd(
+            gr, gd, cr, cd, _p(ln_params), hr, hd, ldh, nr, nd, dgr, dgd, dpr, dpd, _p(pgrad), R, self._stream()), nb),
+            "sgg_lnlstm_gates_bwd")
 
     def colsum(self, X, out, accumulate=False):
         self._dev(X, out)
@@ -500,8 +519,9 @@ class HipKernels:
 
     def adam(self, params, grads, m, v, lr_t, b1, b2, eps, grad_scale=1.0):
         self._dev(params, grads, m, v)
-        self._check(self.lib.sgg_adam_tf_multi(_p(params), _p(grads), _p(m), _p(v), params.numel(), float(lr_t), float(b1),
-                                               float(b2), float(eps), float(grad_scale), self._stream()), "sgg_adam_tf_multi")
+        self._check(self._timed("adam_kernel", 0.0, lambda: self.lib.sgg_adam_tf_multi(
+            _p(params), _p(grads), _p(m), _p(v), params.numel(), float(lr_t), float(b1), float(b2), float(eps), float(grad_scale),
+            self._stream()), 28.0 * params.numel()), "sgg_adam_tf_multi")
 
     def argmax_rows(self, x, out):
         self._dev(x, out)

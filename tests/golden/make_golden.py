@@ -16,9 +16,9 @@ sys.path.insert(0, ROOT)
 from oracle import sgg_oracle as O  # noqa: E402
 
 
-def compute():
+def compute(B=8, S=64, V=50, small=False):
+    """small: keep the file small at full layer shapes (no feature map, only short gradient tensors)."""
     torch.set_num_threads(4)
-    B, S, V = 8, 64, 50
     gp, dp = O.init_params("G", V, S), O.init_params("D", V, S)
     images, labels, onehot = O.synth_batch(B, S, V)
     noise0, noise1, alpha = O.synth_noise(B, 0), O.synth_noise(B, 1), O.synth_alpha(B, 0)
@@ -29,11 +29,12 @@ def compute():
     out["d_real_step0"] = O.discriminator_forward(dp, onehot, images).numpy()
     out["d_fake_step0"] = O.discriminator_forward(dp, fake0, images).numpy()
     feat = O.encoder(gp, images)
-    out["g_downsampled_sample0"] = feat[0].numpy()
+    out["g_downsampled_sample0"] = feat[0].numpy() if not small else feat[0, ::4, ::4, ::16].numpy()
     d_adam, g_adam = O.new_adam_state(dp), O.new_adam_state(gp)
     cost, aux, dgrads = O.d_step(gp, dp, d_adam, 1, images, onehot, noise0, alpha)
     out["disc_cost"] = np.float32(cost)
     out["slopes"] = aux["slopes"].detach().numpy()
+    out["gp"] = np.float32(aux["gp"].detach())
     for n in ("conv2d/kernel", "conv2d_13/bias", "LayerNorm_5/gamma", "layer_norm_basic_lstm_cell/state/beta", "decoder/kernel"):
         out["dgrad/" + n] = dgrads[n].numpy()
     out["dgrad_l1/W"] = np.float32(dgrads["W"].abs().sum())
@@ -48,7 +49,24 @@ def compute():
 
 
 if __name__ == "__main__":
-    o = compute()
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config1_golden.npz")
-    np.savez_compressed(path, **o)
-    print(path, os.path.getsize(path), "bytes")
+    here = os.path.dirname(os.path.abspath(__file__))
+    # BASELINE.json configs[0] (the file name predates the 0-based numbering)
+    todo = [("config1_golden.npz", dict(B=8, S=64, V=50)),
+            # two samples at BASELINE.json configs[1] layer shapes (224x224, vocab 1000)
+            ("configs1_shape_b2_golden.npz", dict(B=2, S=224, V=1000, small=True)),
+            # two samples at configs[4] layer shapes (448x448: L = 784, attention W [401920+512, 784])
+            ("configs4_shape_b2_golden.npz", dict(B=2, S=448, V=50, small=True)),
+            # configs[3] vocabulary (70 000: decoder [512,70000], embedding [70000,300]) on small images
+            ("configs3_vocab_b2_golden.npz", dict(B=2, S=64, V=70000, small=True))]
+    only = sys.argv[1:]
+    for name, kw in todo:
+        if only and name not in only:
+            continue
+        o = compute(**kw)
+        if kw.get("small"):      # [B,3,V] logits at V = 70 000 are kept as a strided sample + the arg-maxed tokens
+            if o["g_logits_step0"].shape[-1] > 2000:
+                o["g_logits_step0"] = o["g_logits_step0"][..., ::97]
+            o.pop("dgrad/decoder/kernel", None)
+        path = os.path.join(here, name)
+        np.savez_compressed(path, **o)
+        print(path, os.path.getsize(path), "bytes")

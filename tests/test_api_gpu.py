@@ -95,6 +95,15 @@ def test_real_data_pipeline_and_evaluation(tmp_path):
     images, labels = gan._next_batch(0)
     assert tuple(images.shape) == (4, 221, 221, 3) and tuple(labels.shape) == (4, 3)
     assert abs(float(images.mean())) < 3.0            # standardised
+    # the prefetching loader (decode threads + pinned double buffer + copy stream) delivers the same batches
+    loader = gan._prefetcher(0, 2, workers=2)
+    im_a, lab_a = next(loader)
+    im_b, lab_b = next(loader)
+    assert torch.equal(im_a, images) and torch.equal(lab_a, labels)
+    images1, labels1 = gan._next_batch(1)
+    assert torch.equal(im_b, images1) and torch.equal(lab_b, labels1)
+    with pytest.raises(StopIteration):
+        next(loader)
     gan.train(max_iterations=1)
     assert torch.isfinite(gan.step.d_losses).all() and os.path.exists(gan._ckpt_path())
     r50, r100 = gan.test(max_images=1, out_path=str(tmp_path / "recalls.txt"))

@@ -27,6 +27,7 @@ from architectures.discriminator_with_attention import Discriminator
 import sgg_amd  # noqa: F401
 from sgg_amd import dp as dpmod
 from sgg_amd.api import kernels_for
+from sgg_amd.data import PrefetchLoader, parse_image
 from sgg_amd.params import EMBED_DIM
 from sgg_amd.step import GanStep
 
@@ -111,11 +112,14 @@ class SceneGraphGAN(object):
         return {"train": (files[:thr], labels[:thr]), "val": (files[thr:], labels[thr:])}
 
     def _parseFunction(self, filename):
-        """JPEG decode -> bilinear resize 221x221 -> (x - mean) / std (train.py:168-174), on the host."""
-        from PIL import Image
-        im = Image.open(filename).convert("RGB").resize((221, 221), Image.BILINEAR)
-        x = torch.from_numpy(np.asarray(im, dtype=np.float32))
-        return (x - self.image_means) / self.image_stds
+        """JPEG decode -> tf.image.resize_images([221, 221]) (TF-1.x bilinear, align_corners=False, no antialiasing) ->
+        (x - mean) / std (train.py:167-172), on the host: sgg_amd/data.py."""
+        return torch.from_numpy(parse_image(filename, self.image_means.numpy(), self.image_stds.numpy()))
+
+    def _batch_indices(self, it):
+        """Example indices of iteration `it` on this rank (rank r takes rows [r*B, (r+1)*B) of the global batch)."""
+        B, n = self.BATCH_SIZE, len(self.dataset["train"][0])
+        return [(it * B * self.world + self.rank * B + j) % n for j in range(B)]
 
     def _next_batch(self, it):
         B = self.BATCH_SIZE
@@ -125,10 +129,17 @@ class SceneGraphGAN(object):
             labels = torch.randint(0, len(self.vocab), (B, 3), generator=g, dtype=torch.int64)
         else:
             files, labs = self.dataset["train"]
-            idx = [(it * B * self.world + self.rank * B + j) % len(files) for j in range(B)]
+            idx = self._batch_indices(it)
             images = torch.stack([self._parseFunction(files[i]) for i in idx])
             labels = torch.from_numpy(labs[idx])
         return images.to(self.device), labels.to(self.device)
+
+    def _prefetcher(self, start, stop, workers=16):
+        """tf.contrib.data.map_and_batch + prefetch (train.py:181-187) as decode threads + a pinned double buffer whose
+        host-to-device copy runs on its own stream while the previous batch trains."""
+        files, labs = self.dataset["train"]
+        return PrefetchLoader(files, labs, self.BATCH_SIZE, self._batch_indices, self.image_means.numpy(), self.image_stds.numpy(),
+                              self.device, stop, start=start, workers=workers)
 
     ############################################################
     ## Saving
@@ -170,8 +181,9 @@ class SceneGraphGAN(object):
         gen = torch.Generator().manual_seed(self.seed + 7 + self.rank)
         log = open(os.path.join(self.summaries_dir, "losses.jsonl"), "a") if self.rank == 0 else None
         B, t0 = self.BATCH_SIZE, time.time()
+        loader = self._prefetcher(self.itr, n_it) if self.dataset is not None else None
         while self.itr < n_it:
-            images, labels = self._next_batch(self.itr)
+            images, labels = next(loader) if loader is not None else self._next_batch(self.itr)
             for _ in range(self.CRITIC_ITERS):                                      # train.py:364-365
                 noise = torch.randn((B, 512), generator=gen).to(self.device)
                 alpha = torch.rand((B,), generator=gen).to(self.device)
@@ -195,7 +207,25 @@ class SceneGraphGAN(object):
     def _recall(self, fake, real, N):
         return float(len(set(map(tuple, fake)).intersection(set(map(tuple, real))))) / N
 
-    def test(self, max_images=None, out_path="recalls.txt"):
+    @staticmethod
+    def _rank(scores, reference_literal=False):
+        """Order of the sampled triples for R@k (train.py:321-323).  Intended semantics (default): ascending mean critic
+        score over the three steps.  reference_literal=True reproduces what the reference's code does: its score array has
+        shape [N, 1] (np.mean(disc_scores, axis=1) of [B, 3, 1], train.py:315), so `argsort()` sorts the length-1 last axis
+        and returns zeros - every "top-k" entry is sample 0 (reference quirk C-11)."""
+        scores = np.asarray(scores, dtype=np.float64).reshape(-1)
+        if reference_literal:
+            return np.zeros(len(scores), dtype=np.int64)
+        return np.argsort(scores, kind="stable")
+
+    def recalls(self, fake, scores, real, reference_literal=False):
+        """(R@50, R@100) of one image: fake [N,3] sampled token triples, scores [N] mean critic outputs, real [M,3] true
+        triples.  Set semantics of train.py:294-295: duplicates collapse, the denominators are the constants 50 and 100."""
+        order = self._rank(scores, reference_literal)
+        fake, real = np.asarray(fake), np.asarray(real, dtype=np.int64).reshape(-1, 3)
+        return self._recall(fake[order[:50]], real, 50.0), self._recall(fake[order[:100]], real, 100.0)
+
+    def test(self, max_images=None, out_path="recalls.txt", reference_literal=False):
         """R@50 / R@100 as the reference computes them: per test image, TEST_BATCH_MULTIPLIER x TEST_BATCH_SIZE
         generator samples, scored by the mean critic output over the three steps, sorted ascending
         (`score_accumulator.argsort()`, train.py:321), the first 50 / 100 compared as sets with the image's true
@@ -227,10 +257,9 @@ class SceneGraphGAN(object):
                 fakes.append(toks.cpu().numpy().copy())
                 scores.append(d.mean(dim=1).reshape(-1).cpu().numpy())
             fake, score = np.concatenate(fakes)[:n_samples], np.concatenate(scores)[:n_samples]
-            order = score.argsort()
-            real = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
-            r50.append(self._recall(fake[order[:50]], real, 50.0))
-            r100.append(self._recall(fake[order[:100]], real, 100.0))
+            a, b = self.recalls(fake, score, triples, reference_literal)
+            r50.append(a)
+            r100.append(b)
         res = (float(np.mean(r50)), float(np.mean(r100)))
         if self.rank == 0 and out_path:
             with open(out_path, "w") as f:
