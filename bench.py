@@ -10,7 +10,10 @@ gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed reg
 
   value / ms_per_step   the timed region (default conv contraction mode, see DTYPE_NAME)
   roofline              dominant convolution kernel against the MFMA peak (live HIP events around its launches)
-  roofline_hbm          the memory-bound kernels (LSTM gates, attention, attention product, LayerNorm, Adam) against HBM peak
+  roofline_hbm          the memory-bound kernels (LSTM gates, attention, attention product, LayerNorm, Adam) against HBM peak,
+                        from HIP events around every such call in two extra steps of the same workload right after the timed
+                        region (the timed region itself brackets only the convolution launches: ~150 more event pairs per step
+                        in the launch-bound head would cost about 1 % of the headline)
   native_f32            the same workload re-timed in the same run with native f32 MFMA arithmetic (mode 0)
   parity                same-run checks: default mode vs native f32 (logits, tokens) and both vs the CPU oracle
   cpu_baseline          the CPU oracle timed on this box's host cores (same run, N = 1 only)
@@ -233,7 +236,7 @@ def main():
     reducer = dpmod.GradReducer() if world > 1 else None
     gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer,
                  overlap_streams=args.overlap_streams)
-    extra = (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0)
+    extra = 2 + (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0)
     total_steps = args.warmup + args.steps
     images, labels, noises, alphas = synth_inputs(B * world, S, V, (total_steps + extra) * (CI + 1), rank, world, dev)
 
@@ -249,10 +252,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(k0, n, with_events):
+    def timed(k0, n, with_events, conv_only=True):
         """n steps bracketed by barrier + synchronize on both sides; max over ranks."""
         barrier()
         K.timing = [] if with_events else None
+        K.timing_conv_only = conv_only
         t0 = time.perf_counter()
         for k in range(k0, k0 + n):
             one_step(k)
@@ -272,6 +276,10 @@ def main():
     dt, timing = timed(args.warmup, args.steps, not args.no_kernel_timing)
     d_losses, g_losses = gs.d_losses.cpu().tolist(), gs.g_losses.cpu().tolist()
     next_k = total_steps
+    timing_hbm, hbm_steps = None, 2
+    if not args.no_kernel_timing:
+        _, timing_hbm = timed(next_k, hbm_steps, True, conv_only=False)
+        next_k += hbm_steps
 
     out = None
     if rank == 0:
@@ -290,7 +298,7 @@ def main():
         if timing:
             per = summarise_timing(timing)
             out["roofline"] = conv_roofline(per, K.conv_precision, dt)
-            out["roofline_hbm"] = hbm_rooflines(per, args.steps)
+            out["roofline_hbm"] = hbm_rooflines(summarise_timing(timing_hbm), hbm_steps)
             out["kernel_time_s"] = {s: round(v[3], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][3])}
             out["kernel_tflops"] = {s: round(v[1] / v[3] / 1e12, 2) for s, v in per.items() if v[3] > 0 and v[1] > 0}
             if args.per_shape:     # per (kernel, FLOPs per launch) = per layer and direction

@@ -120,7 +120,8 @@ class HipKernels:
             raise SggError("no HIP device visible: the scene-graph-gan_amd product path has no CPU fallback")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self._ws_by_stream = {}
-        self.timing = None      # bench.py sets this to a list: conv launches are then bracketed by HIP events
+        self.timing = None      # bench.py sets this to a list: launches are then bracketed by HIP events
+        self.timing_conv_only = False   # True: only the MFMA-bound convolution calls are bracketed (the timed region of bench.py)
         # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
         #   2 (default) f32 operands scaled by a per-tensor power of two and split into two fp16 pieces (22 significant
         #               bits), 3 fp16 MFMAs per product, f32 accumulate: error against fp64 equal to the native f32 path's;
@@ -135,7 +136,7 @@ class HipKernels:
     def _timed(self, symbol, flops, fn, nbytes=0.0):
         """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline legs).
         flops / nbytes: ALGORITHMIC work of the call (MFMA-bound convs: flops; HBM-bound kernels: bytes)."""
-        if self.timing is None:
+        if self.timing is None or (self.timing_conv_only and flops <= 0.0):
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(self.device))
