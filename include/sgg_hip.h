@@ -44,7 +44,10 @@ int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; ze
 /* Halo-resident kernel for the 3x3 stride-1 layers (generator_with_attention.py:31-57: conv1_2, conv2_1..2_4, conv3_1,
  * conv3_2) in precision 2 / 3: sgg_conv_wsplit_layout returns 1 where it applies (H % 8 == W % 8 == 0); the pre-split weights
  * must then be in MFMA fragment order (sgg_conv_split_weights_frag over the [taps][N][C] tensor: the HWOI transpose for the
- * forward, the HWIO kernel for dgrad) and w_split_layout = 1 is passed to sgg_conv2d_nhwc_fwd / _dgrad.  Layout 0 = planes. */
+ * forward, the HWIO kernel for dgrad) and w_split_layout = 1 is passed to sgg_conv2d_nhwc_fwd / _dgrad.  Layout 0 = planes.
+ * Band-resident kernel for the 5x5 stride-2 layers (generator_with_attention.py:35,50,65,68: conv2_5, conv3_5, `downsampled`;
+ * conv1_3 has too few channels for its 128-column tile) on even grids: sgg_conv_wsplit_layout returns 2 (H, W = the full-resolution
+ * grid; ask with (Cin, Cout) swapped for the dgrad direction); weights in the same fragment order with taps = 25. */
 /* The library reads no environment variables and keeps no mutable global state: every kernel choice is a function of the
  * arguments (w_split_layout here, `algo` of sgg_conv2d_nhwc_wgrad). */
 int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);

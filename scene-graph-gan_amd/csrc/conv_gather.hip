@@ -780,6 +780,10 @@ extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout,
     if (!sgg_halo_applicable(KH, KW, stride, Ho, Wo, Cin, Cout, precision)) return 0;
     return (Ho * Wo / 64) * (Cout / sgg_halo_stats_cols(Cout));
   }
+  if (w_split_layout == 2) {
+    if (!sgg_s2_applicable(KH, KW, stride, 1, 2 * Ho, 2 * Wo, Cin, Cout, precision)) return 0;
+    return sgg_s2_stats_per_sample(Ho, Wo, Cout);
+  }
   const int bm = (Cout % 128 == 0) ? 128 : 256;
   const int bn = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0 ? 64 : 32);
   if ((Ho * Wo) % bm != 0) return 0;
@@ -820,6 +824,22 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(halo)");
+    return SGG_OK;
+  }
+  if (w_split_layout == 2) {        // band-resident 5x5 stride-2 kernel (conv_s2.hip), weights in MFMA fragment order (25 taps)
+    SGG_CHECK_ARG(w_split && sgg_s2_applicable(KH, KW, stride, B, Hi, Wi, Cin, Cout, precision) && pad_t == 1 && pad_l == 1,
+                  "sgg_conv2d_nhwc_fwd: w_split_layout 2 needs 5x5 stride 2 on an even grid, Cout %% 128 == 0, precision 2 or 3 "
+                  "(sgg_conv_wsplit_layout)");
+    SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull && (size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull,
+                  "sgg_conv2d_nhwc_fwd: tensor exceeds 2 GiB");
+    SGG_CHECK_ARG(!tile_stats || sgg_s2_stats_per_sample(Ho, Wo, Cout) > 0, "sgg_conv2d_nhwc_fwd: tile_stats need Ho*Wo %% 224 == 0 here");
+    S2Params q;
+    q.src = x; q.wfrag = w_split; q.bias = bias; q.out = y; q.amax_src = amax_x; q.amax_w = amax_w; q.tile_stats = tile_stats;
+    q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cin; q.N = Cout; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo + 2;
+    q.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
+    q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
+    sgg_s2_launch(q, 0, precision, st);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(s2)");
     return SGG_OK;
   }
   GatherParams p;
@@ -867,6 +887,22 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
     sgg_halo_launch(h, precision, (hipStream_t)stream);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(halo)");
+    return SGG_OK;
+  }
+  if (w_split_layout == 2) {        // band-resident 5x5 stride-2 kernel: the four pixel parities of dx from resident dy patches
+    SGG_CHECK_ARG(w_split && sgg_s2_applicable(KH, KW, stride, B, Hi, Wi, Cout, Cin, precision) && pad_t == 1 && pad_l == 1 &&
+                      Hi == 2 * Ho && Wi == 2 * Wo,
+                  "sgg_conv2d_nhwc_dgrad: w_split_layout 2 needs 5x5 stride 2 on an even grid, Cin %% 128 == 0, precision 2 or 3 "
+                  "(sgg_conv_wsplit_layout)");
+    SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull && (size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull,
+                  "sgg_conv2d_nhwc_dgrad: tensor exceeds 2 GiB");
+    S2Params q;
+    q.src = dy; q.wfrag = w_split; q.bias = nullptr; q.out = dx; q.amax_src = amax_dy; q.amax_w = amax_w; q.tile_stats = nullptr;
+    q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cout; q.N = Cin; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo + 2;
+    q.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
+    q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
+    sgg_s2_launch(q, 1, precision, (hipStream_t)stream);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(s2)");
     return SGG_OK;
   }
   GatherParams p;

@@ -41,3 +41,27 @@ int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, 
 void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,
                            int pad_t, int pad_l, int precision, const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl,
                            hipStream_t st);
+
+// ---- band-resident 5x5 stride-2 convolution, forward and dgrad (conv_s2.hip) -----------------------------------------
+struct S2Params {
+  const float* src;       // forward: x [B, 2*Ho, 2*Wo, C];  dgrad: dy [B, Ho, Wo, C]
+  const void* wfrag;      // 25 taps as MFMA B fragments (sgg_conv_split_weights_frag with taps = 25)
+  const float* bias;      // forward only, may be null
+  float* out;             // forward: y [B, Ho, Wo, N];  dgrad: dx [B, 2*Ho, 2*Wo, N]
+  const float* amax_src;
+  const float* amax_w;
+  float* tile_stats;      // forward, optional: (count, mean, M2) per (band, 32 output channels)
+  int B, Ho, Wo;          // the half-resolution grid (forward: output positions; dgrad: dy positions)
+  int C, N;               // contraction channels, output channels
+  int M;                  // B * Ho * Wo
+  int nbands;             // ceil(M / 224)
+  int pitch;              // Wo + 2: slots per patch row
+  unsigned src_bytes, w_bytes;
+  int gx;                 // workgroups per XCD (set by sgg_s2_launch)
+};
+// 1 if the band-resident kernel serves this 5x5 / stride-2 / SAME convolution (Hi, Wi = the full-resolution grid, both even;
+// C = contraction channels, N = output channels of the direction asked for)
+int sgg_s2_applicable(int KH, int KW, int stride, int B, int Hi, int Wi, int C, int N, int precision);
+// (count, mean, M2) partials per sample the forward emits, 0 if bands do not align with samples
+int sgg_s2_stats_per_sample(int Ho, int Wo, int N);
+void sgg_s2_launch(const S2Params& p, int dgrad, int precision, hipStream_t st);

@@ -458,8 +458,12 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
 // Which operand format sgg_conv2d_nhwc_fwd / _dgrad want for the pre-split weights of this convolution:
 // 0 = planes [P][taps*N*C] (sgg_conv_split_weights), 1 = MFMA fragment order (sgg_conv_split_weights_frag; the
 // halo-resident 3x3 stride-1 kernel).  H, W: the (identical) input and output grid of a stride-1 convolution.
+// 2 = MFMA fragment order with 25 taps for the band-resident 5x5 stride-2 kernel (conv_s2.hip); H, W: the full-resolution grid
+// (forward input / dgrad output); for the dgrad direction pass (Cin, Cout) swapped, as for layout 1.
 extern "C" int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision) {
-  return sgg_halo_applicable(KH, KW, stride, H, W, Cin, Cout, precision);
+  if (sgg_halo_applicable(KH, KW, stride, H, W, Cin, Cout, precision)) return 1;
+  if (sgg_s2_applicable(KH, KW, stride, 1, H, W, Cin, Cout, precision)) return 2;
+  return 0;
 }
 
 // in: f32 [taps][N][C] (forward: the HWOI transpose, N = Cout, C = Cin; dgrad: the HWIO kernel, N = Cin, C = Cout)

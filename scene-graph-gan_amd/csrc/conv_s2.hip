@@ -1,0 +1,414 @@
+// Band-resident 5x5 / stride-2 convolution for the split 16-bit modes (gfx950): forward and dgrad of
+//   tf.layers.conv2d(kernel_size=5, strides=2, padding="same")   reference: architectures/generator_with_attention.py:35,50,65,68
+// (conv1_3, conv2_5, conv3_5, `downsampled` and their Conv2DBackpropInput, train.py:265-266) on even input sizes
+// (SAME pads (1,2)).
+//
+// The gather kernel (conv_gather.hip) re-stages a shifted, strided input tile for each of the 25 taps: 25/4 global reads
+// and f32 -> fp16 splits per input element.  Here the stride-2 convolution is taken apart by the PARITY of the input pixel:
+// with X_q(a, c) = x(2a + qy, 2c + qx) (four half-resolution sub-images),
+//     y(oy, ox) = sum over classes q, sum over (u, v) in {-1,0,1}^2 or a subset:  X_q(oy + u, ox + v) . w(kh(u,qy), kw(v,qx))
+// which is a 3x3 / 3x2 / 2x3 / 2x2 stride-1 correlation per class (9 + 6 + 6 + 4 = 25 taps).  The gradient w.r.t. x has the
+// same shape read the other way: the pixels of dx with parity q are a stride-1 correlation of dy with the taps of class q.
+//
+//   * Output positions are the FLAT index p over [B][Ho][Wo] of the half-resolution grid, cut into bands of 224 = 7 MFMA
+//     row tiles of 32: no tile is wasted on 28x28 or 14x14 grids (bands may cross rows and images).
+//   * Per (16-channel chunk, class) the rows of X_q (forward) or dy (dgrad) that a band touches, plus one halo row / column
+//     on each side, are loaded, split into two fp16 planes and written to LDS ONCE (double buffered); every tap of the class
+//     reads its MFMA A fragments from that patch at a shifted slot.  Patch rows live in a "padded row space"
+//     (image b, row a  ->  b*(Ho+2) + a + 1), so the zero rows above / below an image are ordinary patch rows and a band
+//     that crosses from one image into the next needs no special case.
+//   * Weights are MFMA B fragments in L2 (sgg_conv_split_weights_frag, 25 taps), prefetched one tap ahead into registers.
+//   * A workgroup = 4 waves = one band x 128 output channels; every wave holds the band's 7 row tiles for its 32 channels
+//     (112 accumulator registers); the four waves share the patch.
+// LDS image: plane[pp][slot][16 channels] = 32-B slots; the two 16-B halves of a slot are swapped when bit 3 of the slot
+// index is set, which makes the ds_read_b128 of 32 consecutive slots conflict free (lane groups of MI355X_MICROARCH.md, LDS).
+#include "split16.h"
+#include "conv_halo.h"
+#include <type_traits>
+
+#define S2_MT 7
+#define S2_BAND (32 * S2_MT)
+#define S2_MAXSLOTS 496               // 2 buffers x 2 planes x 496 x 32 B + the row tables stay inside 64 KB of static LDS
+#define S2_PLB (S2_MAXSLOTS * 32)      // bytes of one plane of one patch buffer
+#define S2_NPASS 4                     // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256
+#define S2_BN 128
+
+namespace {
+
+// taps of a parity class along one axis: kernel index and patch shift (0..2; the band's own row / column is shift 1)
+//   forward, parity 1: k = 0, 2, 4 at shifts 0, 1, 2      parity 0: k = 1, 3 at shifts 1, 2
+//   dgrad,   parity 1: k = 0, 2, 4 at shifts 2, 1, 0      parity 0: k = 1, 3 at shifts 1, 0
+template <bool DGRAD>
+struct Axis {
+  static constexpr int count(int par) { return par ? 3 : 2; }
+  static constexpr int k(int par, int j) { return par ? 2 * j : 2 * j + 1; }
+  static constexpr int shift(int par, int j) { return DGRAD ? (par ? 2 - j : 1 - j) : (par ? j : j + 1); }
+};
+// class 0 = (qy 1, qx 1): 9 taps, 1 = (1, 0): 6, 2 = (0, 1): 6, 3 = (0, 0): 4
+constexpr int cls_qy(int cls) { return cls < 2 ? 1 : 0; }
+constexpr int cls_qx(int cls) { return (cls & 1) ? 0 : 1; }
+constexpr int cls_ntaps(int cls) { return (cls_qy(cls) ? 3 : 2) * (cls_qx(cls) ? 3 : 2); }
+
+}  // namespace
+
+template <bool DGRAD, bool HALF>
+__global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
+  constexpr int P = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * S2_PLB];
+  __shared__ __attribute__((aligned(16))) int rowtab[2][S2_BAND];      // byte offset of each band row in `out` (-1: past the end)
+
+  // ---- persistent workgroup: XCD k owns a contiguous eighth of the bands; its p.gx workgroups walk (band, n-tile) pairs -----
+  const int ntn = p.N / S2_BN;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nt = jx % ntn;
+  const int bstride = p.gx / ntn;
+  const int band_begin = (int)(((long long)xcd * p.nbands) >> 3) + jx / ntn;
+  const int band_end = (int)(((long long)(xcd + 1) * p.nbands) >> 3);
+  if (band_begin >= band_end) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = nt * S2_BN + wave * 32;                     // this wave's 32 output channels
+  const int i = lane & 31, h = lane >> 5;
+
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
+  int ea = 0, eb = 0;
+  if constexpr (HALF) {
+    ea = scale_exp_from_amax(*p.amax_src);
+    eb = scale_exp_from_amax(*p.amax_w);
+  }
+  const float sa = ldexpf(1.f, ea);
+  const float us_a = ldexpf(1.f, -ea), us_b = ldexpf(1.f, -eb);
+  const int Hp = p.Ho + 2;                                   // padded rows per image
+  const int nch = p.C >> 4;                                  // 16-channel chunks (even: C % 32 == 0)
+  const int nstage = 4 * nch;
+
+  // ---- staging plan: item = (slot, half); static per thread: patch row / column and LDS byte offset -----------------------
+  // (patch row / column are recomputed once per band and the LDS offset per write: cheaper than 12 live registers)
+  // staging state (runs ahead of the compute state): band, stage inside the band, per-item source offsets of that band
+  int s_band = band_begin, s_stage = 0;
+  unsigned s_base[S2_NPASS];
+  auto band_geometry = [&](int band, int& pg_first, int& nrows) __attribute__((always_inline)) {
+    const int p0 = band * S2_BAND;
+    const int p1 = min(p0 + S2_BAND, p.M) - 1;
+    const int g0 = p0 / p.Wo, g1 = p1 / p.Wo;                // first / last global output row of the band
+    const int b0 = g0 / p.Ho, b1 = g1 / p.Ho;
+    pg_first = b0 * Hp + (g0 - b0 * p.Ho);                   // padded row of the halo row above the first row
+    nrows = (b1 * Hp + (g1 - b1 * p.Ho) + 2) - pg_first + 1;
+  };
+  auto stage_band = [&](int band) __attribute__((always_inline)) {
+    if (band >= band_end) {
+#pragma unroll
+      for (int j = 0; j < S2_NPASS; ++j) s_base[j] = SGG_OOB;
+      return;
+    }
+    int pg_first, nrows;
+    band_geometry(band, pg_first, nrows);
+#pragma unroll
+    for (int j = 0; j < S2_NPASS; ++j) {
+      const int slot = (tid + 256 * j) >> 1, half = tid & 1;
+      const int lr = slot / p.pitch, lc = slot - lr * p.pitch;
+      const int pg = pg_first + lr;
+      const int b = pg / Hp;
+      const int a = pg - b * Hp - 1, c = lc - 1;
+      const bool ok = (lr < nrows) & (b < p.B) & (a >= 0) & (a < p.Ho) & (c >= 0) & (c < p.Wo);
+      const unsigned off = DGRAD ? (unsigned)((((b * p.Ho + a) * p.Wo + c) * p.C + half * 8) * 4)
+                                 : (unsigned)((((b * 2 * p.Ho + 2 * a) * 2 * p.Wo + 2 * c) * p.C + half * 8) * 4);
+      s_base[j] = ok ? off : SGG_OOB;
+    }
+  };
+  f32x4 pre[S2_NPASS][2];
+  // issue the global loads of the next (band, stage) patch; then advance the staging state
+  auto stage_load = [&]() __attribute__((always_inline)) {
+    int cls, cc;
+    if constexpr (DGRAD) { cls = s_stage / nch; cc = s_stage - cls * nch; }
+    else { cc = s_stage >> 2; cls = s_stage & 3; }
+    (void)cls;
+    unsigned uni = (unsigned)(cc * 64);
+    if constexpr (!DGRAD) uni += (unsigned)((((cls < 2 ? 1 : 0) * 2 * p.Wo + ((cls & 1) ? 0 : 1)) * p.C) * 4);
+#pragma unroll
+    for (int j = 0; j < S2_NPASS; ++j) {
+      const unsigned off = s_base[j] == SGG_OOB ? SGG_OOB : s_base[j] + uni;
+      pre[j][0] = buf_load4(rs_src, off);
+      pre[j][1] = buf_load4(rs_src, off + 16u);
+    }
+    if (++s_stage == nstage) {
+      s_stage = 0;
+      s_band += bstride;
+      stage_band(s_band);
+    }
+  };
+  auto stage_write = [&](unsigned char* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < S2_NPASS; ++j) {
+      u32x4 pl[P];
+      split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
+      if (tid + 256 * j < 2 * S2_MAXSLOTS) {
+        const int slot = (tid + 256 * j) >> 1;
+        const int lds_off = slot * 32 + (((tid & 1) ^ ((slot >> 3) & 1)) << 4);
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * S2_PLB + lds_off) = pl[pp];
+      }
+    }
+  };
+
+  // ---- weights: B fragments from L2, layout [tap][C/32][N/32][k-step][plane][lane] x 16 B (16-channel chunk cc = 2*c32 + k-step)
+  const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)lane * 16u;
+  const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
+  const int nch32 = p.C >> 5;
+  u32x4 rb[2][P];
+  auto load_b = [&](auto par_c, int cc, int tap) __attribute__((always_inline)) {
+    constexpr int par = decltype(par_c)::value;
+    const unsigned base = (unsigned)(tap * nch32 + (cc >> 1)) * w_slab + (unsigned)((cc & 1) * 2048) + w_lane;
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) rb[par][pp] = __builtin_bit_cast(u32x4, buf_load4(rs_w, base + (unsigned)(pp * 1024)));
+  };
+
+  f32x16 acc[S2_MT];
+#pragma unroll
+  for (int t = 0; t < S2_MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int slot0[S2_MT];          // patch slot of this lane's output position in row tile t (the centre of its 3x3 neighbourhood)
+  int cur = 0;               // patch buffer the current stage reads
+  float bias_v = 0.f;
+  if constexpr (!DGRAD) bias_v = p.bias ? p.bias[n0 + i] : 0.f;
+
+  // A fragments go through a ring of three register sets: the fragments of row tile k+2 (of this tap or the next one) are
+  // read from the resident patch while the MFMAs of tile k issue, so an LDS latency is exposed only at the start of a stage.
+  u32x4 ra[3][P];
+  auto read_a = [&](auto ring_c, auto t_c, int shift) __attribute__((always_inline)) {
+    constexpr int ring = decltype(ring_c)::value, t = decltype(t_c)::value;
+    // (opaque to the optimiser: otherwise the 175 per-tap LDS addresses, invariant across the chunk loop, are hoisted and spilled)
+    int sc = slot0[t];
+    asm volatile("" : "+v"(sc));
+    const int s = sc + shift;
+    const unsigned char* a_ptr = lds + cur * (P * S2_PLB) + s * 32 + ((h ^ ((s >> 3) & 1)) << 4);
+    ra[ring][0] = *reinterpret_cast<const u32x4*>(a_ptr);
+    ra[ring][1] = *reinterpret_cast<const u32x4*>(a_ptr + S2_PLB);
+  };
+  auto mma_tile = [&](auto ring_c, auto t_c, auto par_c) __attribute__((always_inline)) {
+    constexpr int ring = decltype(ring_c)::value, t = decltype(t_c)::value, par = decltype(par_c)::value;
+    f32x16 d = acc[t];
+    d = mfma16<HALF>(ra[ring][1], rb[par][0], d);
+    d = mfma16<HALF>(ra[ring][0], rb[par][1], d);
+    d = mfma16<HALF>(ra[ring][0], rb[par][0], d);
+    acc[t] = d;
+  };
+
+  // One stage = one (16-channel chunk, class): its taps statically unrolled.  Every tap prefetches the next tap's B fragments
+  // (next_tap / next_cc: first tap of the following stage); the next stage's patch is loaded three taps before the end and
+  // split + written to the other buffer during the last tap.
+  auto stage = [&](auto cls_c, auto par0_c, int cc, int next_cc, int next_tap) __attribute__((always_inline)) {
+    constexpr int cls = decltype(cls_c)::value, par0 = decltype(par0_c)::value;
+    constexpr int qy = cls_qy(cls), qx = cls_qx(cls);
+    constexpr int ny = Axis<DGRAD>::count(qy), nx = Axis<DGRAD>::count(qx), ntaps = ny * nx;
+    auto tap_shift = [&](auto ti_c) __attribute__((always_inline)) {
+      constexpr int ti = decltype(ti_c)::value;
+      return (Axis<DGRAD>::shift(qy, ti / nx) - 1) * p.pitch + (Axis<DGRAD>::shift(qx, ti % nx) - 1);
+    };
+    read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, tap_shift(std::integral_constant<int, 0>{}));
+    read_a(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, tap_shift(std::integral_constant<int, 0>{}));
+    auto body = [&](auto ti_c) __attribute__((always_inline)) {
+      constexpr int ti = decltype(ti_c)::value;
+      constexpr int par = (par0 + ti) & 1;
+      if constexpr (ti + 1 < ntaps) {
+        constexpr int njy = (ti + 1) / nx, njx = (ti + 1) % nx;
+        load_b(std::integral_constant<int, par ^ 1>{}, cc, Axis<DGRAD>::k(qy, njy) * 5 + Axis<DGRAD>::k(qx, njx));
+      } else {
+        load_b(std::integral_constant<int, par ^ 1>{}, next_cc, next_tap);
+      }
+      if constexpr (ti == (ntaps >= 6 ? ntaps - 3 : 1)) stage_load();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ti == ntaps - 1) stage_write(lds + (cur ^ 1) * (P * S2_PLB));
+      auto tile = [&](auto t_c) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int k = ti * S2_MT + t;
+        if constexpr (k + 2 < ntaps * S2_MT) {
+          constexpr int nti = (k + 2) / S2_MT, nt2 = (k + 2) % S2_MT;
+          read_a(std::integral_constant<int, (k + 2) % 3>{}, std::integral_constant<int, nt2>{}, tap_shift(std::integral_constant<int, nti>{}));
+        }
+        mma_tile(std::integral_constant<int, k % 3>{}, t_c, std::integral_constant<int, par>{});
+      };
+      tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{});
+      tile(std::integral_constant<int, 3>{}); tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
+      tile(std::integral_constant<int, 6>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    body(std::integral_constant<int, 0>{}); body(std::integral_constant<int, 1>{});
+    body(std::integral_constant<int, 2>{}); body(std::integral_constant<int, 3>{});
+    if constexpr (ntaps > 4) { body(std::integral_constant<int, 4>{}); body(std::integral_constant<int, 5>{}); }
+    if constexpr (ntaps > 6) { body(std::integral_constant<int, 6>{}); body(std::integral_constant<int, 7>{}); body(std::integral_constant<int, 8>{}); }
+    cur ^= 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  constexpr int TAP0[4] = {Axis<DGRAD>::k(1, 0) * 5 + Axis<DGRAD>::k(1, 0), Axis<DGRAD>::k(1, 0) * 5 + Axis<DGRAD>::k(0, 0),
+                           Axis<DGRAD>::k(0, 0) * 5 + Axis<DGRAD>::k(1, 0), Axis<DGRAD>::k(0, 0) * 5 + Axis<DGRAD>::k(0, 0)};
+
+  // ---- epilogue: unscale (+ bias), store through the band's row table; forward: optional LayerNorm partials ----------------
+  auto epilogue = [&](int band, int tabsel, int cls_off_bytes) __attribute__((always_inline)) {
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < S2_MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = HALF ? fmaf(acc[t][r] * us_a, us_b, bias_v) : acc[t][r] + bias_v;
+        acc[t][r] = v;
+        lsum += v;
+      }
+    char* ob = reinterpret_cast<char*>(p.out) + cls_off_bytes + (size_t)(n0 + i) * 4;
+#pragma unroll
+    for (int t = 0; t < S2_MT; ++t)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int4 o4 = *reinterpret_cast<const int4*>(&rowtab[tabsel][t * 32 + rq * 8 + 4 * h]);
+        if (o4.x >= 0) *reinterpret_cast<float*>(ob + o4.x) = acc[t][rq * 4 + 0];
+        if (o4.y >= 0) *reinterpret_cast<float*>(ob + o4.y) = acc[t][rq * 4 + 1];
+        if (o4.z >= 0) *reinterpret_cast<float*>(ob + o4.z) = acc[t][rq * 4 + 2];
+        if (o4.w >= 0) *reinterpret_cast<float*>(ob + o4.w) = acc[t][rq * 4 + 3];
+      }
+    if constexpr (!DGRAD) {
+      if (p.tile_stats) {
+        // (count, mean, M2) of this wave's 224 positions x 32 channels (bands align with samples: host check)
+        const float cnt = (float)(S2_BAND * 32);
+        const float mean_w = wave_sum(lsum) / cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < S2_MT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[t][r] - mean_w;
+            q += d * d;
+          }
+        q = wave_sum(q);
+        if (lane == 0) {
+          float* o = p.tile_stats + ((size_t)band * (p.N >> 5) + (n0 >> 5)) * 3;
+          o[0] = cnt;
+          o[1] = mean_w;
+          o[2] = q;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < S2_MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  };
+
+  // ---- prologue: first patch, first B fragments ----------------------------------------------------------------------------
+  stage_band(s_band);
+  stage_load();
+  load_b(std::integral_constant<int, 0>{}, 0, TAP0[0]);
+  stage_write(lds);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int tabsel = 0;
+  for (int band = band_begin; band < band_end; band += bstride, tabsel ^= 1) {
+    // compute state of this band: row table (out offsets) and the per-lane patch slots of the 7 row tiles
+    int pg_first, nrows;
+    band_geometry(band, pg_first, nrows);
+    const int p0 = band * S2_BAND;
+    if (tid < S2_BAND) {
+      const int pp = p0 + tid;
+      int off = -1;
+      if (pp < p.M) {
+        if constexpr (DGRAD) {
+          const int g = pp / p.Wo, ox = pp - g * p.Wo;
+          const int b = g / p.Ho, oy = g - b * p.Ho;
+          off = (((b * 2 * p.Ho + 2 * oy) * 2 * p.Wo + 2 * ox) * p.N) * 4;
+        } else {
+          off = pp * p.N * 4;
+        }
+      }
+      rowtab[tabsel][tid] = off;
+    }
+#pragma unroll
+    for (int t = 0; t < S2_MT; ++t) {
+      const int pp = min(p0 + t * 32 + i, p.M - 1);
+      const int g = pp / p.Wo, ox = pp - g * p.Wo;
+      const int b = g / p.Ho, oy = g - b * p.Ho;
+      slot0[t] = (b * Hp + oy + 1 - pg_first) * p.pitch + ox + 1;
+    }
+    // (the row table is read after at least one workgroup barrier: every stage ends with one)
+    if constexpr (!DGRAD) {
+      for (int cc = 0; cc < nch; cc += 2) {
+        const bool last = cc + 2 >= nch;
+        stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, cc, cc, TAP0[1]);
+        stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cc, cc, TAP0[2]);
+        stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, cc, cc, TAP0[3]);
+        stage(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, cc, cc + 1, TAP0[0]);
+        stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, cc + 1, cc + 1, TAP0[1]);
+        stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, cc + 1, cc + 1, TAP0[2]);
+        stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, cc + 1, cc + 1, TAP0[3]);
+        stage(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, cc + 1, last ? 0 : cc + 2, TAP0[0]);
+      }
+      epilogue(band, tabsel, 0);
+    } else {
+      auto class_loop = [&](auto cls_c) __attribute__((always_inline)) {
+        constexpr int cls = decltype(cls_c)::value;
+        constexpr int odd = cls_ntaps(cls) & 1;
+        constexpr int ncls = (cls + 1) & 3;
+        for (int cc = 0; cc < nch; cc += 2) {
+          const bool last = cc + 2 >= nch;
+          stage(cls_c, std::integral_constant<int, 0>{}, cc, cc + 1, TAP0[cls]);
+          stage(cls_c, std::integral_constant<int, odd>{}, cc + 1, last ? 0 : cc + 2, last ? TAP0[ncls] : TAP0[cls]);
+        }
+        epilogue(band, tabsel, ((cls_qy(cls) * 2 * p.Wo + cls_qx(cls)) * p.N) * 4);
+      };
+      class_loop(std::integral_constant<int, 0>{});
+      class_loop(std::integral_constant<int, 1>{});
+      class_loop(std::integral_constant<int, 2>{});
+      class_loop(std::integral_constant<int, 3>{});
+    }
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------
+static int s2_gcd(int a, int b) { return b ? s2_gcd(b, a % b) : a; }
+
+// largest number of patch rows any band needs (the band pattern repeats every 224 / gcd(224, Ho*Wo) images)
+static int s2_max_rows(int Ho, int Wo) {
+  const int period = S2_BAND / s2_gcd(S2_BAND, Ho * Wo);
+  const long long M = (long long)period * Ho * Wo;
+  int mx = 0;
+  for (long long p0 = 0; p0 < M; p0 += S2_BAND) {
+    const long long p1 = (p0 + S2_BAND < M ? p0 + S2_BAND : M) - 1;
+    const int g0 = (int)(p0 / Wo), g1 = (int)(p1 / Wo);
+    const int b0 = g0 / Ho, b1 = g1 / Ho;
+    const int rows = (b1 * (Ho + 2) + (g1 - b1 * Ho) + 2) - (b0 * (Ho + 2) + (g0 - b0 * Ho)) + 1;
+    if (rows > mx) mx = rows;
+  }
+  return mx;
+}
+
+int sgg_s2_applicable(int KH, int KW, int stride, int B, int Hi, int Wi, int C, int N, int precision) {
+  (void)B;
+  if (!(KH == 5 && KW == 5 && stride == 2 && Hi > 0 && Wi > 0 && Hi % 2 == 0 && Wi % 2 == 0 && C % 32 == 0 && N % S2_BN == 0 &&
+        (precision == 2 || precision == 3)))
+    return 0;
+  const int Ho = Hi / 2, Wo = Wi / 2;
+  return s2_max_rows(Ho, Wo) * (Wo + 2) <= S2_MAXSLOTS;
+}
+
+int sgg_s2_stats_per_sample(int Ho, int Wo, int N) { return ((Ho * Wo) % S2_BAND == 0) ? (Ho * Wo / S2_BAND) * (N / 32) : 0; }
+
+void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st) {
+  S2Params p = p_;
+  const int ntn = p.N / S2_BN;
+  int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile) pairs an XCD owns
+  int gx = per_xcd < 64 ? per_xcd : 64;            // two resident workgroups on each of its 32 CUs
+  gx = sgg_cdiv(gx, ntn) * ntn;
+  p.gx = gx;
+  const dim3 grid((unsigned)(8 * gx));
+  const bool half = precision == 2;
+  if (dgrad) {
+    if (half) hipLaunchKernelGGL((conv_s2_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_s2_kernel<true, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (half) hipLaunchKernelGGL((conv_s2_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_s2_kernel<false, false>), grid, dim3(256), 0, st, p);
+  }
+}

@@ -220,8 +220,9 @@ class HipKernels:
         return w
 
     def conv_wsplit_layout(self, k, stride, H, W, cin, cout):
-        """Layout the conv entry points want for the pre-split weights of this layer: 0 = planes, 1 = MFMA fragment order
-        (halo-resident 3x3 stride-1 kernel; SGG_CONV_HALO=0 keeps every layer on the gather kernel)."""
+        """Layout the conv entry points want for the pre-split weights of this layer: 0 = planes, 1 / 2 = MFMA fragment order
+        (1: halo-resident 3x3 stride-1 kernel, 2: band-resident 5x5 stride-2 kernel; H, W = the full-resolution grid;
+        SGG_CONV_HALO=0 keeps every layer on the gather kernel)."""
         if not self.conv_halo:
             return 0
         return self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
@@ -230,7 +231,7 @@ class HipKernels:
         """w fp32 [kh, kw, N, C] -> out int16 [P, n] sixteen-bit planes (layout 0) or MFMA B fragments (layout 1)."""
         self._dev(w, out, amax)
         amax = self._amax_or_compute(w, amax, 2)
-        if layout == 1:
+        if layout in (1, 2):
             kh, kw, n, c = w.shape
             self._check(self.lib.sgg_conv_split_weights_frag(_p(w), _p(out), kh * kw, n, c, self.conv_precision, _p(amax),
                                                              self._stream()), "sgg_conv_split_weights_frag")
@@ -248,6 +249,9 @@ class HipKernels:
         return "conv_halo3_kernel<%s,%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
                                                    "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false", "true" if n_in == 32 else "false")
 
+    def s2_symbol(self, dgrad):
+        return "conv_s2_kernel<%s,%s>" % ("true" if dgrad else "false", "true" if self.conv_precision == 2 else "false")
+
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
         self._dev(x, w_fwd, bias, y)
@@ -255,6 +259,7 @@ class HipKernels:
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3]) if w_split_layout == 1 else
+                                                             self.s2_symbol(False) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
@@ -268,7 +273,8 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else self.gather_symbol(d[3], w_split is not None)
+        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.s2_symbol(True) if w_split_layout == 2 else
+                                                                          self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),
             self._stream())), "sgg_conv2d_nhwc_dgrad")

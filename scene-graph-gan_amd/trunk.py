@@ -77,7 +77,8 @@ class Trunk:
             k, s = lay["k"], lay["s"]
             lay["ws_layout"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cin"], lay["cout"])
             ho, wo = lay["out_shape"][1], lay["out_shape"][2]
-            lay["ws_layout_bwd"] = K.conv_wsplit_layout(k, s, ho, wo, lay["cout"], lay["cin"]) if s == 1 else 0
+            # (both directions are asked with the full-resolution grid: forward input = dgrad output)
+            lay["ws_layout_bwd"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cout"], lay["cin"])
 
     def _f16(self):
         return getattr(self.K, "conv_precision", 0) == 2

@@ -23,11 +23,22 @@ wf = torch.empty((k, k, Co, Ci), device="cuda"); K.hwio_to_hwoi(w, wf)
 lay = K.conv_wsplit_layout(k, s, H, H, Ci, Co)
 am = torch.zeros(2, device="cuda"); K.absmax(x, am[0:1]); K.absmax(w, am[1:2])
 ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+lay_b = K.conv_wsplit_layout(k, s, H, H, Co, Ci)
+amdy = torch.zeros(1, device="cuda"); K.absmax(dy, amdy)
 if mode == "fwd_ws": K.split_weights(wf, ws, am[1:2], lay)
+if mode == "dgrad_ws": K.split_weights(w, ws, am[1:2], lay_b)
+ws0 = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+if mode == "fwd_gather_ws": K.split_weights(wf, ws0, am[1:2], 0)
+if mode == "dgrad_gather_ws": K.split_weights(w, ws0, am[1:2], 0)
 def run():
     if mode == "fwd": K.conv_fwd(x, w, wf, b, y, s)
     elif mode == "fwd_ws": K.conv_fwd(x, w, wf, b, y, s, ws, am[0:1], am[1:2], None, lay)
     elif mode == "dgrad": K.conv_dgrad(dy, w, dx, s)
+    elif mode == "dgrad_ws": K.conv_dgrad(dy, w, dx, s, ws, amdy, am[1:2], lay_b)
+    elif mode == "fwd_gather_ws":
+        K.conv_fwd(x, w, wf, b, y, s, ws0, am[0:1], am[1:2], None, 0)
+    elif mode == "dgrad_gather_ws":
+        K.conv_dgrad(dy, w, dx, s, ws0, amdy, am[1:2], 0)
     else: K.conv_wgrad(x, dy, dw, s)
 run(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

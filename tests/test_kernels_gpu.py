@@ -488,3 +488,72 @@ def test_conv_epilogue_layernorm_stats(hip, ref, cout):
     a_ref, st_ref = torch.empty_like(y_ref), torch.empty((B, 2), dtype=torch.float64)
     ref.ln_elu_fwd(y_ref, gamma.double(), beta.double(), a_ref, st_ref)
     close(a1, a_ref, rtol=5e-5, what="conv + LN vs fp64")
+
+
+S2_CASES = [
+    # B, H (= W, even), Cin, Cout   (5x5, stride 2: the half-resolution grid is H/2 x H/2, cut into flat bands of 224 positions)
+    (2, 16, 32, 128),       # 128 positions: one ragged band holding two images
+    (3, 28, 64, 128),       # 14x14 grid: bands cross image boundaries (2.6 bands)
+    (2, 56, 128, 256),      # 28x28 grid: band 3 takes rows 24..27 of image 0 and 0..3 of image 1; two n-tiles
+    (1, 112, 32, 128),      # 56x56 grid: 14 aligned bands of four rows (LayerNorm partials available)
+    (2, 24, 32, 128),       # 12x12 grid: bands start in the middle of a row
+    (5, 28, 256, 512),      # 980 positions, ragged last band, four n-tiles, 16 chunks
+]
+
+
+@pytest.mark.parametrize("mode", [2, 3], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
+    """Band-resident 5x5 stride-2 kernel (csrc/conv_s2.hip) vs the fp64 reference and vs the gather kernel."""
+    from tests import conv_ref64 as R64
+    B, H, Ci, Co = case
+    old = hip.conv_precision
+    hip.conv_precision = mode
+    try:
+        tol = {2: 2e-5, 3: 1e-4}[mode]
+        assert hip.conv_wsplit_layout(5, 2, H, H, Ci, Co) == 2
+        assert hip.conv_wsplit_layout(5, 2, H + 1, H, Ci, Co) == 0          # odd sizes have different SAME pads: gather kernel
+        assert hip.conv_wsplit_layout(5, 2, 8, 8, Ci, Co) == 0              # 4x4 grid: a band would span 14 images
+        x, w, b = rnd((B, H, H, Ci), 11), rnd((5, 5, Ci, Co), 12, 1.0 / math.sqrt(25 * Ci)), rnd((Co,), 13, 0.1)
+        Ho = H // 2
+        dy = rnd((B, Ho, Ho, Co), 14)
+        y_ref = R64.conv_fwd64(x.double(), w.double(), b.double(), 2)
+        xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+        wf = torch.empty((5, 5, Co, Ci), device="cuda")
+        hip.hwio_to_hwoi(wd, wf)
+        ws_f = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+        hip.split_weights(wf, ws_f, layout=2)
+        y = torch.full((B, Ho, Ho, Co), float("nan"), device="cuda")
+        hip.conv_fwd(xd, wd, wf, bd, y, 2, ws_f, w_split_layout=2)
+        close(y, y_ref, rtol=tol, what="s2 conv_fwd %s" % (case,))
+        y_g = torch.empty_like(y)
+        hip.conv_fwd(xd, wd, wf, bd, y_g, 2)
+        close(y, y_g.cpu(), rtol=5e-6, what="s2 vs gather (forward)")
+        if hip.conv_wsplit_layout(5, 2, H, H, Co, Ci) == 2:                  # dgrad direction: output channels = Cin
+            dx_ref = R64.conv_dgrad64(dy.double(), w.double(), (H, H), 2)
+            ws_b = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+            hip.split_weights(wd, ws_b, layout=2)
+            dx = torch.full((B, H, H, Ci), float("nan"), device="cuda")
+            hip.conv_dgrad(dyd, wd, dx, 2, ws_b, w_split_layout=2)
+            close(dx, dx_ref, rtol=tol, what="s2 conv_dgrad %s" % (case,))
+            dx_g = torch.empty_like(dx)
+            hip.conv_dgrad(dyd, wd, dx_g, 2)
+            close(dx, dx_g.cpu(), rtol=5e-6, what="s2 vs gather (dgrad)")
+        else:
+            assert Ci % 128 != 0
+        nts = hip.conv_tile_stats_count((B, Ho, Ho, Co), Ci, 5, 2, 2)
+        assert nts == ((Ho * Ho // 224) * (Co // 32) if (Ho * Ho) % 224 == 0 else 0)
+        if nts:
+            ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+            y2 = torch.empty_like(y)
+            hip.conv_fwd(xd, wd, wf, bd, y2, 2, ws_f, tile_stats=ts, w_split_layout=2)
+            assert torch.equal(y2, y)
+            gamma, beta = dev(1.0 + rnd((Co,), 15, 0.2)), dev(rnd((Co,), 16, 0.2))
+            a1, a2 = torch.empty_like(y), torch.empty_like(y)
+            st1, st2 = torch.empty((B, 2), device="cuda"), torch.empty((B, 2), device="cuda")
+            hip.ln_elu_fwd(y, gamma, beta, a1, st1, tile_stats=ts)
+            hip.ln_elu_fwd(y, gamma, beta, a2, st2)
+            close(st1, st2.cpu(), rtol=1e-6, what="stats from the s2 epilogue vs statistics pass")
+            close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+    finally:
+        hip.conv_precision = old
