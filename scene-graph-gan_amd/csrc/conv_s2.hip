@@ -26,8 +26,7 @@
 #include "conv_halo.h"
 #include <type_traits>
 
-#define S2_MT 7
-#define S2_BAND (32 * S2_MT)
+#define S2_BAND 224                   // positions per band in the 7-tile variant (what LayerNorm partials are defined on)
 #define S2_MAXSLOTS 496               // 2 buffers x 2 planes x 496 x 32 B + the row tables stay inside 64 KB of static LDS
 #define S2_PLB (S2_MAXSLOTS * 32)      // bytes of one plane of one patch buffer
 #define S2_NPASS 4                     // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256
@@ -51,11 +50,14 @@ constexpr int cls_ntaps(int cls) { return (cls_qy(cls) ? 3 : 2) * (cls_qx(cls) ?
 
 }  // namespace
 
-template <bool DGRAD, bool HALF>
+// MT = MFMA row tiles per band: 7 (224 positions), or 4 (128 positions) where 224-position bands would give fewer
+// (band, n-tile) work items than the chip has CUs (`downsampled` at batch 64: 56 bands x 4 n-tiles).
+template <bool DGRAD, bool HALF, int MT>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   constexpr int P = 2;
+  constexpr int BAND = 32 * MT;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * S2_PLB];
-  __shared__ __attribute__((aligned(16))) int rowtab[2][S2_BAND];      // byte offset of each band row in `out` (-1: past the end)
+  __shared__ __attribute__((aligned(16))) int rowtab[2][BAND];      // byte offset of each band row in `out` (-1: past the end)
 
   // ---- persistent workgroup: XCD k owns a contiguous eighth of the bands; its p.gx workgroups walk (band, n-tile) pairs -----
   const int ntn = p.N / S2_BN;
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   int s_band = band_begin, s_stage = 0;
   unsigned s_base[S2_NPASS];
   auto band_geometry = [&](int band, int& pg_first, int& nrows) __attribute__((always_inline)) {
-    const int p0 = band * S2_BAND;
-    const int p1 = min(p0 + S2_BAND, p.M) - 1;
+    const int p0 = band * BAND;
+    const int p1 = min(p0 + BAND, p.M) - 1;
     const int g0 = p0 / p.Wo, g1 = p1 / p.Wo;                // first / last global output row of the band
     const int b0 = g0 / p.Ho, b1 = g1 / p.Ho;
     pg_first = b0 * Hp + (g0 - b0 * p.Ho);                   // padded row of the halo row above the first row
@@ -164,13 +166,13 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     for (int pp = 0; pp < P; ++pp) rb[par][pp] = __builtin_bit_cast(u32x4, buf_load4(rs_w, base + (unsigned)(pp * 1024)));
   };
 
-  f32x16 acc[S2_MT];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int t = 0; t < S2_MT; ++t)
+  for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  int slot0[S2_MT];          // patch slot of this lane's output position in row tile t (the centre of its 3x3 neighbourhood)
+  int slot0[MT];          // patch slot of this lane's output position in row tile t (the centre of its 3x3 neighbourhood)
   int cur = 0;               // patch buffer the current stage reads
   float bias_v = 0.f;
   if constexpr (!DGRAD) bias_v = p.bias ? p.bias[n0 + i] : 0.f;
@@ -224,16 +226,17 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       if constexpr (ti == ntaps - 1) stage_write(lds + (cur ^ 1) * (P * S2_PLB));
       auto tile = [&](auto t_c) __attribute__((always_inline)) {
         constexpr int t = decltype(t_c)::value;
-        constexpr int k = ti * S2_MT + t;
-        if constexpr (k + 2 < ntaps * S2_MT) {
-          constexpr int nti = (k + 2) / S2_MT, nt2 = (k + 2) % S2_MT;
+        constexpr int k = ti * MT + t;
+        if constexpr (k + 2 < ntaps * MT) {
+          constexpr int nti = (k + 2) / MT, nt2 = (k + 2) % MT;
           read_a(std::integral_constant<int, (k + 2) % 3>{}, std::integral_constant<int, nt2>{}, tap_shift(std::integral_constant<int, nti>{}));
         }
         mma_tile(std::integral_constant<int, k % 3>{}, t_c, std::integral_constant<int, par>{});
       };
       tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{});
-      tile(std::integral_constant<int, 3>{}); tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
-      tile(std::integral_constant<int, 6>{});
+      tile(std::integral_constant<int, 3>{});
+      if constexpr (MT > 4) { tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{}); tile(std::integral_constant<int, 6>{}); }
+      static_assert(MT == 4 || MT == 7, "row tiles per band");
       __builtin_amdgcn_sched_barrier(0);
     };
     body(std::integral_constant<int, 0>{}); body(std::integral_constant<int, 1>{});
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   auto epilogue = [&](int band, int tabsel, int cls_off_bytes) __attribute__((always_inline)) {
     float lsum = 0.f;
 #pragma unroll
-    for (int t = 0; t < S2_MT; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = HALF ? fmaf(acc[t][r] * us_a, us_b, bias_v) : acc[t][r] + bias_v;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       }
     char* ob = reinterpret_cast<char*>(p.out) + cls_off_bytes + (size_t)(n0 + i) * 4;
 #pragma unroll
-    for (int t = 0; t < S2_MT; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int4 o4 = *reinterpret_cast<const int4*>(&rowtab[tabsel][t * 32 + rq * 8 + 4 * h]);
@@ -272,11 +275,11 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     if constexpr (!DGRAD) {
       if (p.tile_stats) {
         // (count, mean, M2) of this wave's 224 positions x 32 channels (bands align with samples: host check)
-        const float cnt = (float)(S2_BAND * 32);
+        const float cnt = (float)(BAND * 32);
         const float mean_w = wave_sum(lsum) / cnt;
         float q = 0.f;
 #pragma unroll
-        for (int t = 0; t < S2_MT; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float d = acc[t][r] - mean_w;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       }
     }
 #pragma unroll
-    for (int t = 0; t < S2_MT; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   };
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     // compute state of this band: row table (out offsets) and the per-lane patch slots of the 7 row tiles
     int pg_first, nrows;
     band_geometry(band, pg_first, nrows);
-    const int p0 = band * S2_BAND;
-    if (tid < S2_BAND) {
+    const int p0 = band * BAND;
+    if (tid < BAND) {
       const int pp = p0 + tid;
       int off = -1;
       if (pp < p.M) {
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       rowtab[tabsel][tid] = off;
     }
 #pragma unroll
-    for (int t = 0; t < S2_MT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       const int pp = min(p0 + t * 32 + i, p.M - 1);
       const int g = pp / p.Wo, ox = pp - g * p.Wo;
       const int b = g / p.Ho, oy = g - b * p.Ho;
@@ -370,12 +373,12 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
 static int s2_gcd(int a, int b) { return b ? s2_gcd(b, a % b) : a; }
 
 // largest number of patch rows any band needs (the band pattern repeats every 224 / gcd(224, Ho*Wo) images)
-static int s2_max_rows(int Ho, int Wo) {
-  const int period = S2_BAND / s2_gcd(S2_BAND, Ho * Wo);
+static int s2_max_rows(int Ho, int Wo, int band = S2_BAND) {
+  const int period = band / s2_gcd(band, Ho * Wo);
   const long long M = (long long)period * Ho * Wo;
   int mx = 0;
-  for (long long p0 = 0; p0 < M; p0 += S2_BAND) {
-    const long long p1 = (p0 + S2_BAND < M ? p0 + S2_BAND : M) - 1;
+  for (long long p0 = 0; p0 < M; p0 += band) {
+    const long long p1 = (p0 + band < M ? p0 + band : M) - 1;
     const int g0 = (int)(p0 / Wo), g1 = (int)(p1 / Wo);
     const int b0 = g0 / Ho, b1 = g1 / Ho;
     const int rows = (b1 * (Ho + 2) + (g1 - b1 * Ho) + 2) - (b0 * (Ho + 2) + (g0 - b0 * Ho)) + 1;
@@ -398,17 +401,26 @@ int sgg_s2_stats_per_sample(int Ho, int Wo, int N) { return ((Ho * Wo) % S2_BAND
 void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st) {
   S2Params p = p_;
   const int ntn = p.N / S2_BN;
+  // 224-position bands unless they give fewer work items than CUs (and no LayerNorm partials are asked for): then 128
+  const int mt = (!p.tile_stats && sgg_cdiv(p.M, S2_BAND) * ntn <= 256) ? 4 : 7;
+  p.nbands = sgg_cdiv(p.M, 32 * mt);
   int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile) pairs an XCD owns
   int gx = per_xcd < 64 ? per_xcd : 64;            // two resident workgroups on each of its 32 CUs
   gx = sgg_cdiv(gx, ntn) * ntn;
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx));
   const bool half = precision == 2;
-  if (dgrad) {
-    if (half) hipLaunchKernelGGL((conv_s2_kernel<true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_s2_kernel<true, false>), grid, dim3(256), 0, st, p);
-  } else {
-    if (half) hipLaunchKernelGGL((conv_s2_kernel<false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_s2_kernel<false, false>), grid, dim3(256), 0, st, p);
-  }
+#define SGG_S2(MT)                                                                                      \
+  do {                                                                                                  \
+    if (dgrad) {                                                                                        \
+      if (half) hipLaunchKernelGGL((conv_s2_kernel<true, true, MT>), grid, dim3(256), 0, st, p);        \
+      else hipLaunchKernelGGL((conv_s2_kernel<true, false, MT>), grid, dim3(256), 0, st, p);            \
+    } else {                                                                                            \
+      if (half) hipLaunchKernelGGL((conv_s2_kernel<false, true, MT>), grid, dim3(256), 0, st, p);       \
+      else hipLaunchKernelGGL((conv_s2_kernel<false, false, MT>), grid, dim3(256), 0, st, p);           \
+    }                                                                                                   \
+  } while (0)
+  if (mt == 4) SGG_S2(4);
+  else SGG_S2(7);
+#undef SGG_S2
 }

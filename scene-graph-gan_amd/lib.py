@@ -249,8 +249,10 @@ class HipKernels:
         return "conv_halo3_kernel<%s,%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
                                                    "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false", "true" if n_in == 32 else "false")
 
-    def s2_symbol(self, dgrad):
-        return "conv_s2_kernel<%s,%s>" % ("true" if dgrad else "false", "true" if self.conv_precision == 2 else "false")
+    def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True):
+        """(csrc/conv_s2.hip: sgg_s2_launch picks 128-position bands when 224-position ones give at most 256 work items)"""
+        mt = 4 if (not stats and -(-m_positions // 224) * (n_out // 128) <= 256) else 7
+        return "conv_s2_kernel<%s,%s,%d>" % ("true" if dgrad else "false", "true" if self.conv_precision == 2 else "false", mt)
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
@@ -259,7 +261,7 @@ class HipKernels:
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3]) if w_split_layout == 1 else
-                                                             self.s2_symbol(False) if w_split_layout == 2 else
+                                                             self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
@@ -273,7 +275,7 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.s2_symbol(True) if w_split_layout == 2 else
+        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False) if w_split_layout == 2 else
                                                                           self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),

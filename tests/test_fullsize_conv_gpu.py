@@ -73,6 +73,25 @@ def run_modes(hip, x, w, b, dy, s, what, do=("fwd", "dgrad", "wgrad")):
                 hip.conv_dgrad(dyd, wd, dx, s)
                 out["dgrad"][mode] = rel_err(dx, refs["dgrad"])
                 del dx
+            if mode == 2:
+                # the product path: pre-split weights in the layout the trunk uses (halo-resident 3x3 / band-resident 5x5
+                # stride-2 kernels where they apply); same bound as the gather kernel
+                for op, (ci, co, wsrc) in (("fwd", (w.shape[2], w.shape[3], wf)), ("dgrad", (w.shape[3], w.shape[2], wd))):
+                    if op not in refs:
+                        continue
+                    lay = hip.conv_wsplit_layout(k, s, H, W, ci, co)
+                    ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+                    hip.split_weights(wsrc, ws, layout=lay)
+                    o = torch.full(tuple(refs[op].shape), float("nan"), device="cuda")
+                    if op == "fwd":
+                        hip.conv_fwd(xd, wd, wf, bd, o, s, ws, w_split_layout=lay)
+                    else:
+                        hip.conv_dgrad(dyd, wd, o, s, ws, w_split_layout=lay)
+                    e = rel_err(o, refs[op])
+                    print("%-34s %-5s err f16x3 product path (weight layout %d) %.3e" % (what, op, lay, e))
+                    ERRORS["%s/%s" % (what, op + "_layout%d" % lay)] = {"f16x3": e}
+                    out[op][2] = max(out[op][2], e)
+                    del o, ws
             if "wgrad" in refs:
                 dw = torch.full(tuple(w.shape), float("nan"), device="cuda")
                 hip.conv_wgrad(xd, dyd, dw, s)
