@@ -54,9 +54,16 @@ int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, in
 int sgg_conv_split_weights_frag(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
-                        const float* amax_x, const float* amax_w, float* tile_stats, void* stream);
-/* tile_stats (optional): the epilogue also writes (count, mean, M2) of every output tile, [B][n][3] with
- * n = sgg_conv2d_nhwc_fwd_tile_stats(...) > 0; pass them to sgg_layernorm_hwc_elu_fwd to skip its statistics pass. */
+                        const float* amax_x, const float* amax_w, float* tile_stats, const float* ln_stats, const float* ln_gamma,
+                        const float* ln_beta, void* stream);
+/* tile_stats (optional): the epilogue also writes (count, mean, M2, max |y - mean|) of every output tile, [B][n][4] with
+ * n = sgg_conv2d_nhwc_fwd_tile_stats(...) > 0; pass them to sgg_layernorm_hwc_elu_fwd to skip its statistics pass, or to
+ * sgg_layernorm_hwc_finalize when the consumer applies the LayerNorm itself:
+ * LN prologue (ln_stats / ln_gamma / ln_beta, optional, w_split_layout 1 only; also on sgg_conv2d_nhwc_wgrad where its halo-resident
+ * kernel applies): x is the PRE-LayerNorm output y of the producing convolution and the kernel computes
+ * ELU((y - mean_b) * rstd_b * gamma_c + beta_c) while it stages its input patch (tf.contrib.layers.layer_norm(activation_fn=elu),
+ * generator_with_attention.py:30..56), so the LayerNorm apply pass and the activation tensor are never written.  ln_stats [B][2] =
+ * (mean, rstd) from sgg_layernorm_hwc_finalize; amax_x must then be the word that call published (an upper bound of max|a|). */
 int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision, int w_split_layout);
 /* Conv2DBackpropInput: dx from dy and the HWIO kernel */
 int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
@@ -67,7 +74,8 @@ int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_sp
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int Hi, int Wi, int Cin, int Ho,
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int algo,
-                          const float* amax_x, const float* amax_dy, void* workspace, size_t workspace_bytes, void* stream);
+                          const float* amax_x, const float* amax_dy, const float* ln_stats, const float* ln_gamma, const float* ln_beta,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- tf.contrib.layers.layer_norm(activation_fn=tf.nn.elu) over (H,W,C) per sample ------------------------
  * generator_with_attention.py:30..66 / discriminator_with_attention.py:30..66.  C: power of two in [4,1024].
@@ -78,6 +86,10 @@ size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C);
 int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
                               float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* statistics only: stats[b] = (mean, rstd) merged from the convolution's tile partials; amax_out max-ed with an upper bound of
+ * max|ELU(LN(y))| (for the fp16 scaling of a consumer with an LN prologue) */
+int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_stats, const float* gamma, const float* beta, float* stats,
+                               float* amax_out, int B, int HW, int C, void* stream);
 int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
                               const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
                               float* amax_out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) voi
     if (lane == 0) red[wave] = lsum;
     __syncthreads();
     const float mean_t = (red[0] + red[1] + red[2] + red[3]) * (1.f / (float)(BM * BN));
-    float q = 0.f;
+    float q = 0.f, dm = 0.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -532,17 +532,20 @@ __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) voi
         for (int r = 0; r < 16; ++r) {
           const float d = acc[tm][tn][r] - mean_t;
           q += d * d;
+          dm = fmaxf(dm, fabsf(d));
         }
     q = wave_sum(q);
-    if (lane == 0) red[4 + wave] = q;
+    dm = wave_max(dm);
+    if (lane == 0) { red[4 + wave] = q; red[8 + wave] = dm; }
     __syncthreads();
     if (tid == 0) {
       const int b = m0 / p.hw, t_in = (m0 - b * p.hw) / BM;
       const int tps = p.hw / BM;
-      float* o = p.tile_stats + ((size_t)(b * tps + t_in) * ntiles_n + nt) * 3;
+      float* o = p.tile_stats + ((size_t)(b * tps + t_in) * ntiles_n + nt) * SGG_TS;
       o[0] = (float)(BM * BN);
       o[1] = mean_t;
       o[2] = red[4] + red[5] + red[6] + red[7];
+      o[3] = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
     }
   }
 }
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restric
                                                           int tiles_x, int tiles_y) {
   constexpr int COUT = 32;
   __shared__ __attribute__((aligned(16))) f32x4 patch[10 * 34];
-  __shared__ float red[8];
+  __shared__ float red[12];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = blockIdx.x % tiles_x, t2 = blockIdx.x / tiles_x;
   const int ty = t2 % tiles_y, b = t2 / tiles_y;
@@ -618,21 +621,24 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restric
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const float mean_t = (red[0] + red[1] + red[2] + red[3]) / cnt;
-    float q = 0.f;
+    float q = 0.f, dm = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r)
       if (col_ok && y0 + r < H) {
         const f32x4 d = out[r] - mean_t;
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        dm = fmaxf(fmaxf(dm, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
       }
     q = wave_sum(q);
-    if (lane == 0) red[4 + wave] = q;
+    dm = wave_max(dm);
+    if (lane == 0) { red[4 + wave] = q; red[8 + wave] = dm; }
     __syncthreads();
     if (tid == 0) {
-      float* o = tile_stats + ((size_t)b * tiles_x * tiles_y + ty * tiles_x + tx) * 3;
+      float* o = tile_stats + ((size_t)b * tiles_x * tiles_y + ty * tiles_x + tx) * SGG_TS;
       o[0] = cnt;
       o[1] = mean_t;
       o[2] = red[4] + red[5] + red[6] + red[7];
+      o[3] = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
     }
   }
 }
@@ -794,8 +800,10 @@ extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout,
 extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi,
                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
                                    int precision, int w_split_layout, const float* amax_x, const float* amax_w, float* tile_stats,
-                                   void* stream) {
+                                   const float* ln_stats, const float* ln_gamma, const float* ln_beta, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
+  SGG_CHECK_ARG(!ln_stats || (w_split_layout == 1 && ln_gamma && ln_beta && Cin <= 512),
+                "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1 (halo-resident kernel), gamma, beta and Cin <= 512");
   SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 2, 3 or 6");
   SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 2 needs the amax words");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_fwd: bad dims");
@@ -818,6 +826,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
                   "sgg_conv2d_nhwc_fwd: w_split_layout 1 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
     HaloParams h;
     h.src = x; h.wfrag = w_split; h.bias = bias; h.out = y; h.amax_src = amax_x; h.amax_w = amax_w; h.tile_stats = tile_stats;
+    h.ln_stats = ln_stats; h.ln_gamma = ln_gamma; h.ln_beta = ln_beta;
     h.B = B; h.H = Hi; h.W = Wi; h.C = Cin; h.N = Cout; h.bh = Hi / 8; h.bw = Wi / 8; h.nblk = B * h.bh * h.bw; h.flip = 0;
     h.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
@@ -882,6 +891,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     SGG_CHECK_ARG((size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_dgrad: dy exceeds 2 GiB");
     HaloParams h;
     h.src = dy; h.wfrag = w_split; h.bias = nullptr; h.out = dx; h.amax_src = amax_dy; h.amax_w = amax_w; h.tile_stats = nullptr;
+    h.ln_stats = nullptr; h.ln_gamma = nullptr; h.ln_beta = nullptr;
     h.B = B; h.H = Hi; h.W = Wi; h.C = Cout; h.N = Cin; h.bh = Hi / 8; h.bw = Wi / 8; h.nblk = B * h.bh * h.bw; h.flip = 1;
     h.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));

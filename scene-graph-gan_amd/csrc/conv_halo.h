@@ -10,7 +10,13 @@ struct HaloParams {
   float* out;             // [B, H, W, N]
   const float* amax_src;  // precision 2: device words with max|src| and max|w|
   const float* amax_w;
-  float* tile_stats;      // optional: per (8x8 block, wave column range) (count, mean, M2) for the following LayerNorm
+  float* tile_stats;      // optional: per (8x8 block, wave column range) (count, mean, M2, max dev) for the following LayerNorm
+  // LN prologue (forward only, optional): src holds the PRE-LayerNorm convolution output y of the producing layer; the patch staging
+  // applies a = ELU((y - mean_b) * rstd_b * gamma_c + beta_c) on the fly (ln_stats [B][2] from sgg_layernorm_hwc_finalize), so the
+  // LayerNorm apply pass and the materialised activation are not needed (generator_with_attention.py:30..56)
+  const float* ln_stats;
+  const float* ln_gamma;
+  const float* ln_beta;
   int B, H, W, C, N;
   int bh, bw, nblk;       // 8x8 blocks per image (rows, cols) and in total
   int flip;               // 0: forward (correlation); 1: dgrad (taps mirrored)
@@ -40,7 +46,8 @@ int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, 
 // writes pl.nslabs partial dW slabs [slab][9][Cin][Cout] (unscaled f32) into `slabs`
 void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,
                            int pad_t, int pad_l, int precision, const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl,
-                           hipStream_t st);
+                           hipStream_t st, const float* ln_stats = nullptr, const float* ln_gamma = nullptr,
+                           const float* ln_beta = nullptr);
 
 // ---- band-resident 5x5 stride-2 convolution, forward and dgrad (conv_s2.hip) -----------------------------------------
 struct S2Params {

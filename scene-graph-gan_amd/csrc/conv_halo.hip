@@ -45,7 +45,8 @@ __device__ __forceinline__ int halo_sw(int ry, int rx) { return ((rx >> 2) & 1) 
 // ONECH: C == 32 (one chunk per tile); otherwise C % 64 == 0 (an even number of chunks): the B-fragment double buffer
 // flips once per chunk (nine taps), so chunks are unrolled in pairs - a run-time parity branch between two chunk bodies
 // costs ~110 spilled VGPRs at the merge.
-template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH>
+// LNP: LN prologue - src is the producing layer's pre-LayerNorm output, normalised + ELU'd while the patch is staged.
+template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH, bool LNP>
 __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   constexpr int P = 2;
   constexpr int WN = BN / WGN, TM = 2, TN = WN / 32;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   constexpr int NPASS = (ITEMS + 255) / 256;
   constexpr bool DB = (2 * P * PLANEB <= 65536);        // two patch buffers: one barrier per chunk instead of two
   __shared__ __attribute__((aligned(16))) unsigned char lds[(DB ? 2 : 1) * P * PLANEB];
+  __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 1024 : 4];      // gamma[0..511], beta at +512 (C <= 512: host check)
 
   // ---- persistent workgroup ----------------------------------------------------------------------------------------
   // XCD k (workgroup ids are dealt round-robin to the 8 XCDs) owns a contiguous eighth of the M-tiles (NB blocks each);
@@ -96,8 +98,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     it_rel[j] = (unsigned)(((ry * p.W + rx) * p.C + ch8 * 8) * 4);
     const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
     it_meta[j] = (blk * HALO_BLKB + (ry * HALO_PITCH + rx) * 64 + ((ch8 ^ halo_sw(ry, rx)) << 4)) | (bits << 20) | ((blk & 3) << 24) |
-                 ((it < ITEMS) << 28);
+                 (ch8 << 26) | ((it < ITEMS) << 28);
   }
+  if constexpr (LNP) {
+    for (int c = tid; c < p.C; c += 256) {
+      lnp_s[c] = p.ln_gamma[c];
+      lnp_s[512 + c] = p.ln_beta[c];
+    }
+    __syncthreads();
+  }
+  // LN prologue state of the patch in flight (between stage_load and stage_write): per block the sample's (mean, rstd), the
+  // channel chunk, and which items are padding (must stay a zero activation)
+  float ld_mu[NB], ld_rs[NB];
+  int ld_cc = 0, ld_bad = 0;
 
   // block coordinates of the tile being STAGED (uniform: scalar registers): global block row (b*bh + by), by, bx
   int s_grow[NB], s_by[NB], s_bx[NB];
@@ -125,6 +138,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       // a dead block: every item masked (bits 0 -> use the valid flag below)
       if (dead) base[j] = SGG_OOB;
     }
+    if constexpr (LNP) {
+      ld_cc = s_cc;
+      ld_bad = 0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int b = s_grow[j] / p.bh;
+        b = b < p.B ? b : p.B - 1;
+        ld_mu[j] = p.ln_stats[2 * b];
+        ld_rs[j] = p.ln_stats[2 * b + 1];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
       const int blk = (it_meta[j] >> 24) & 3;
@@ -137,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       }
       const bool bad = !((it_meta[j] >> 28) & 1) | ((((it_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
       const unsigned off = bad ? SGG_OOB : b0 + it_rel[j];
+      if constexpr (LNP) ld_bad |= (int)bad << j;
       pre[j][0] = buf_load4(rs_src, off);
       pre[j][1] = buf_load4(rs_src, off + 16u);
     }
@@ -160,6 +185,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   auto stage_write = [&](unsigned char* dst) {
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
+      if constexpr (LNP) {
+        const int blk = (it_meta[j] >> 24) & 3;
+        float mu = ld_mu[0], rs = ld_rs[0];
+#pragma unroll
+        for (int k = 1; k < NB; ++k) {
+          mu = blk == k ? ld_mu[k] : mu;
+          rs = blk == k ? ld_rs[k] : rs;
+        }
+        const int cb = ld_cc * 32 + ((it_meta[j] >> 26) & 3) * 8;
+        ln_elu8(pre[j][0], pre[j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad >> j) & 1);
+      }
       u32x4 pl[P];
       split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
       if ((it_meta[j] >> 28) & 1) {
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       // (count, mean, M2) of this wave's 64 pixels x WN channels (one 8x8 block: inside one sample); merged per sample
       // with Chan's formula by ln_apply_elu_kernel
       const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));
-      float q = 0.f;
+      float q = 0.f, dm = 0.f;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -351,13 +387,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
           for (int r = 0; r < 16; ++r) {
             const float d = acc[tm][tn][r] - mean_w;
             q += d * d;
+            dm = fmaxf(dm, fabsf(d));
           }
       q = wave_sum(q);
+      dm = wave_max(dm);
       if (lane == 0 && live) {
-        float* o = p.tile_stats + ((size_t)beta * (p.N / WN) + (n0 + wn0) / WN) * 3;
+        float* o = p.tile_stats + ((size_t)beta * (p.N / WN) + (n0 + wn0) / WN) * SGG_TS;
         o[0] = (float)(64 * WN);
         o[1] = mean_w;
         o[2] = q;
+        o[3] = dm;
       }
     }
     acc_zero<TM, TN>(acc);
@@ -444,10 +483,15 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
     gx = sgg_cdiv(gx, ntn) * ntn;                                                                            \
     p.gx = gx;                                                                                               \
     const dim3 grid((unsigned)(8 * gx));                                                                     \
-    if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true>), grid, dim3(256), 0, st, p);        \
-    else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false>), grid, dim3(256), 0, st, p);           \
-    else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true>), grid, dim3(256), 0, st, p);      \
-    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false>), grid, dim3(256), 0, st, p);                    \
+    if (p.ln_stats) {                                                                                                                  \
+      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, true>), grid, dim3(256), 0, st, p);   \
+      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, true>), grid, dim3(256), 0, st, p);      \
+      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, true>), grid, dim3(256), 0, st, p); \
+      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, true>), grid, dim3(256), 0, st, p);               \
+    } else if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false>), grid, dim3(256), 0, st, p); \
+    else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false>), grid, dim3(256), 0, st, p);       \
+    else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false>), grid, dim3(256), 0, st, p);  \
+    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false>), grid, dim3(256), 0, st, p);                \
   } while (0)
   if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true);
   else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false);

@@ -277,20 +277,23 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         // (count, mean, M2) of this wave's 224 positions x 32 channels (bands align with samples: host check)
         const float cnt = (float)(BAND * 32);
         const float mean_w = wave_sum(lsum) / cnt;
-        float q = 0.f;
+        float q = 0.f, dm = 0.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float d = acc[t][r] - mean_w;
             q += d * d;
+            dm = fmaxf(dm, fabsf(d));
           }
         q = wave_sum(q);
+        dm = wave_max(dm);
         if (lane == 0) {
-          float* o = p.tile_stats + ((size_t)band * (p.N >> 5) + (n0 >> 5)) * 3;
+          float* o = p.tile_stats + ((size_t)band * (p.N >> 5) + (n0 >> 5)) * SGG_TS;
           o[0] = cnt;
           o[1] = mean_w;
           o[2] = q;
+          o[3] = dm;
         }
       }
     }

@@ -603,9 +603,10 @@ extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, i
 
 extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int algo,
-                                     const float* amax_x, const float* amax_dy, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     const float* amax_x, const float* amax_dy, const float* ln_stats, const float* ln_gamma,
+                                     const float* ln_beta, void* workspace, size_t workspace_bytes, void* stream) {
   SGG_CHECK_ARG(x && dy && dw, "sgg_conv2d_nhwc_wgrad: null pointer");
+  SGG_CHECK_ARG(!ln_stats || (ln_gamma && ln_beta), "sgg_conv2d_nhwc_wgrad: the LN prologue needs stats, gamma and beta");
   SGG_CHECK_ARG(algo == 0 || algo == 1, "sgg_conv2d_nhwc_wgrad: algo must be 0 (auto) or 1 (per-tap kernels only)");
   SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6,
                 "sgg_conv2d_nhwc_wgrad: precision must be 0, 2, 3 or 6");
@@ -630,12 +631,15 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
       sgg_set_error("sgg_conv2d_nhwc_wgrad: workspace too small (%zu < %zu)", workspace_bytes, hp.ws_bytes);
       return SGG_ERR_WORKSPACE;
     }
-    sgg_wgrad_halo_launch(x, dy, (float*)workspace, B, Ho, Wo, Cin, Cout, stride, pad_t, pad_l, precision, amax_x, amax_dy, hp, st);
+    sgg_wgrad_halo_launch(x, dy, (float*)workspace, B, Ho, Wo, Cin, Cout, stride, pad_t, pad_l, precision, amax_x, amax_dy, hp, st,
+                          ln_stats, ln_gamma, ln_beta);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo)");
     launch_slab_reduce((const float*)workspace, dw, nout / 4, hp.nslabs, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo reduce)");
     return SGG_OK;
   }
+  SGG_CHECK_ARG(!ln_stats, "sgg_conv2d_nhwc_wgrad: the LN prologue is served by the halo-resident kernel only (3x3 stride 1 or 5x5 "
+                           "stride 2 on grids divisible by 8, precision 2 or 3, algo 0)");
   if (Cin == 3) {
     SGG_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && Cout == 32, "sgg_conv2d_nhwc_wgrad: Cin=3 path needs 3x3 s1 Cout=32");
     hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, Hi, Wi, pad_t, pad_l,

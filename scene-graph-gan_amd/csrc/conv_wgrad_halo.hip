@@ -30,6 +30,10 @@ struct WgradHaloParams {
   float* slabs;
   const float* amax_x;
   const float* amax_dy;
+  const float* ln_stats;  // LN prologue (optional): x holds the producing layer's pre-LayerNorm output y; see HaloParams
+  const float* ln_gamma;
+  const float* ln_beta;
+  int B;
   int H, W, C, N;         // dy grid (= output grid of the convolution); C = Cin, N = Cout
   int Hx, Wx;             // x grid (= H, W for stride 1; 2H, 2W for the stride-2 classes)
   int sxy;                // stride (1 or 2)
@@ -45,7 +49,7 @@ struct WgradHaloParams {
 
 // NKH x NKW: taps of the launch (3x3 for the stride-1 kernel; 3x3 / 3x2 / 2x3 / 2x2 for the four parity classes of a 5x5
 // stride-2 kernel, each a stride-1 problem on the sub-sampled x grid).
-template <int CT, int NT, bool HALF, bool PREF, int NKH, int NKW>
+template <int CT, int NT, bool HALF, bool PREF, int NKH, int NKW, bool LNP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParams p) {
   constexpr int NTAP = NKH * NKW;
   constexpr int P = 2;
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   constexpr int DI = 256 * NT, DP = DI / 256;
   constexpr int NPASS = NBS * (XP + DP);
   __shared__ __attribute__((aligned(16))) unsigned char lds[P * (XPLANE + DPLANE)];
+  __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 64 * CT : 4];   // gamma, beta of this workgroup's 32*CT input channels
   unsigned char* x_s = lds;
   unsigned char* d_s = lds + P * XPLANE;
 
@@ -117,6 +122,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
     cx[j] = rem % p.bw;
   }
   int next_beta = blk_begin;       // first block of the stage the next stage_load fetches
+  if constexpr (LNP) {
+    if (tid < 32 * CT) {
+      lnp_s[tid] = p.ln_gamma[c0 + tid];
+      lnp_s[32 * CT + tid] = p.ln_beta[c0 + tid];
+    }
+    __syncthreads();
+  }
+  float ld_mu[NBS], ld_rs[NBS];    // LN prologue: (mean, rstd) of the staged blocks' samples, padding items of the patch in flight
+  int ld_bad = 0;
 
   f32x4 pre[NPASS][2];
   auto stage_load = [&]() {
@@ -127,11 +141,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
       const unsigned xbase = (unsigned)((((cb[blk] * p.Hx + (by * 8 - 1) * p.sxy + p.cy) * p.Wx + (bx * 8 - 1) * p.sxy + p.cx) * p.C + c0) * 4);
       const unsigned dbase = (unsigned)((((cb[blk] * p.H + by * 8) * p.W + bx * 8) * p.N + n0) * 4);
       const int bbits = (by == 0) | ((by == p.bh - 1) << 1) | ((bx == 0) << 2) | ((bx == p.bw - 1) << 3);
+      if constexpr (LNP) {
+        const int b = cb[blk] < p.B ? cb[blk] : p.B - 1;
+        ld_mu[blk] = p.ln_stats[2 * b];
+        ld_rs[blk] = p.ln_stats[2 * b + 1];
+        if (blk == 0) ld_bad = 0;
+      }
 #pragma unroll
       for (int jj = 0; jj < XP + DP; ++jj) {
         const int j = blk * (XP + DP) + jj;
         const bool isx = jj < XP;
         const bool bad = dead | !((it_lds[j] >> 24) & 1) | (isx && (((it_lds[j] >> 20) & 15 & bbits) != 0));
+        if constexpr (LNP) ld_bad |= (int)bad << j;
         const unsigned off = bad ? SGG_OOB : (isx ? xbase : dbase) + it_rel[j];
         if (isx) {
           pre[j][0] = buf_load4(rs_x, off);
@@ -154,6 +175,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
       const bool isx = (j % (XP + DP)) < XP;
+      if constexpr (LNP) {
+        if (isx) {
+          const int blk = j / (XP + DP), i = tid + 256 * (j % (XP + DP));
+          const int cbx = (i / 400) * 32 + ((i % 400) & 3) * 8;
+          ln_elu8(pre[j][0], pre[j][1], lnp_s + cbx, lnp_s + 32 * CT + cbx, ld_mu[blk], ld_rs[blk], (ld_bad >> j) & 1);
+        }
+      }
       u32x4 pl[P];
       split8<P, HALF>(pre[j][0], pre[j][1], isx ? sa : sb, pl);
       if ((it_lds[j] >> 24) & 1) {
@@ -268,8 +296,11 @@ static void wgrad_halo_launch_class(const WgradHaloParams& p, const WgradHaloPla
   const dim3 grid(pl.nsplit, pl.pairs);
 #define SGG_WH(CT, NT, PF)                                                                                          \
   do {                                                                                                              \
-    if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF, NKH, NKW>), grid, dim3(256), 0, st, p);   \
-    else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF, NKH, NKW>), grid, dim3(256), 0, st, p);       \
+    if (p.ln_stats) {                                                                                               \
+      if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF, NKH, NKW, true>), grid, dim3(256), 0, st, p);   \
+      else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF, NKH, NKW, true>), grid, dim3(256), 0, st, p);       \
+    } else if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF, NKH, NKW, false>), grid, dim3(256), 0, st, p);   \
+    else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF, NKH, NKW, false>), grid, dim3(256), 0, st, p);       \
   } while (0)
   if (pl.ct == 2) SGG_WH(2, 2, true);
   else if (pl.nt == 2) SGG_WH(1, 2, false);
@@ -280,9 +311,10 @@ static void wgrad_halo_launch_class(const WgradHaloParams& p, const WgradHaloPla
 // stride: 1 (3x3) or 2 (5x5, one launch per parity class of the taps); pad_t / pad_l: SAME padding before
 void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,
                            int pad_t, int pad_l, int precision, const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl,
-                           hipStream_t st) {
+                           hipStream_t st, const float* ln_stats, const float* ln_gamma, const float* ln_beta) {
   WgradHaloParams p;
   p.x = x; p.dy = dy; p.slabs = slabs; p.amax_x = amax_x; p.amax_dy = amax_dy;
+  p.ln_stats = ln_stats; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.B = B;
   p.H = H; p.W = W; p.C = Cin; p.N = Cout; p.bh = H / 8; p.bw = W / 8; p.nblk = B * p.bh * p.bw;
   p.Hx = H * stride; p.Wx = W * stride; p.sxy = stride;
   p.pairs_n = pl.pairs_n; p.stages = pl.stages;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_stats_partial_kernel(const float* __re
   __shared__ float red[4];
   const int b = blockIdx.y, g = blockIdx.x;
   const float* yb = y + (size_t)b * N;
-  float n_run = 0.f, mean_run = 0.f, m2_run = 0.f;
+  float n_run = 0.f, mean_run = 0.f, m2_run = 0.f, dev_run = 0.f;   // dev_run: max |y - running mean| bound
   for (int c = 0; c < cpg; ++c) {
     const long long base = ((long long)g * cpg + c) * LN_CHUNK;
     if (base >= N) break;
@@ -58,25 +58,35 @@ __global__ __launch_bounds__(256) void ln_stats_partial_kernel(const float* __re
     }
     const float n_c = (float)((N - base) < LN_CHUNK ? (N - base) : LN_CHUNK);
     const float mean_c = block_sum_256(s, red) / n_c;
-    float q = 0.f;
+    float q = 0.f, dm = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = base + (threadIdx.x + 256 * j) * 4;
       if (e < N) {
         const f32x4 d = v[j] - mean_c;
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        dm = fmaxf(fmaxf(dm, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
       }
     }
     const float m2_c = block_sum_256(q, red);
     const float n_new = n_run + n_c;
     const float delta = mean_c - mean_run;
-    mean_run += delta * (n_c / n_new);
+    const float mean_new = mean_run + delta * (n_c / n_new);
+    // |y - mean_new| <= max|y - own chunk mean| + |own chunk mean - mean_new| for the elements of either part
+    dm = wave_max(dm);
+    dev_run = fmaxf(dev_run + fabsf(mean_run - mean_new), dm + fabsf(mean_c - mean_new));
+    mean_run = mean_new;
     m2_run += m2_c + delta * delta * (n_run * n_c / n_new);
     n_run = n_new;
   }
+  // (dev_run holds a per-wave maximum: combine the four waves)
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dev_run;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    float* o = part + ((size_t)b * G + g) * 3;
+    float* o = part + ((size_t)b * G + g) * SGG_TS;
     o[0] = n_run; o[1] = mean_run; o[2] = m2_run;
+    o[3] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
 }
 
@@ -84,12 +94,12 @@ __global__ __launch_bounds__(256) void ln_stats_partial_kernel(const float* __re
 __device__ __forceinline__ void ln_merge(const float* __restrict__ part, int G, float N, float* red, float& mean,
                                          float& rstd) {
   float s = 0.f;
-  for (int i = threadIdx.x; i < G; i += 256) s += part[i * 3 + 0] * part[i * 3 + 1];
+  for (int i = threadIdx.x; i < G; i += 256) s += part[i * SGG_TS + 0] * part[i * SGG_TS + 1];
   mean = block_sum_256(s, red) / N;
   float q = 0.f;
   for (int i = threadIdx.x; i < G; i += 256) {
-    const float d = part[i * 3 + 1] - mean;
-    q += part[i * 3 + 2] + part[i * 3 + 0] * d * d;
+    const float d = part[i * SGG_TS + 1] - mean;
+    q += part[i * SGG_TS + 2] + part[i * SGG_TS + 0] * d * d;
   }
   const float var = block_sum_256(q, red) / N;
   rstd = rsqrtf(var + LN_EPS);
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restri
   const int b = blockIdx.y, g = blockIdx.x;
   float mean, rstd;
   float amax = 0.f;
-  ln_merge(part + (size_t)b * G * 3, G, (float)N, red, mean, rstd);
+  ln_merge(part + (size_t)b * G * SGG_TS, G, (float)N, red, mean, rstd);
   if (g == 0 && threadIdx.x == 0) {
     stats[b * 2 + 0] = mean;
     stats[b * 2 + 1] = rstd;
@@ -133,6 +143,40 @@ __global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restri
     }
   }
   if (amax_out) block_publish_amax(amax_out, amax, red);   // max |a| (the consumer convolution's f16 scaling)
+}
+
+// Statistics only (no apply pass): stats[b] = (mean, rstd) merged from the partials, and an UPPER BOUND of max |ELU(LN(y))|
+// published into amax_out: |a| <= |z| = |gamma_c * xhat + beta_c| <= max|gamma| * max|y - mean| * rstd + max|beta|, with
+// max|y - mean| <= max over tiles of (tile deviation + |tile mean - mean|).  Consumers that normalise y on the fly
+// (sgg_conv2d_nhwc_fwd / _wgrad with an LN prologue) scale their fp16 pieces with it.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int G, float N, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int C, float* __restrict__ stats,
+                                                          float* __restrict__ amax_out) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* pb = part + (size_t)b * G * SGG_TS;
+  float mean, rstd;
+  ln_merge(pb, G, N, red, mean, rstd);
+  float dev = 0.f, gb = 0.f, bb = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) dev = fmaxf(dev, pb[i * SGG_TS + 3] + fabsf(pb[i * SGG_TS + 1] - mean));
+  for (int c = threadIdx.x; c < C; c += 256) {
+    gb = fmaxf(gb, fabsf(gamma[c]));
+    bb = fmaxf(bb, fabsf(beta[c]));
+  }
+  dev = wave_max(dev); gb = wave_max(gb); bb = wave_max(bb);
+  __shared__ float mx[3][4];
+  if ((threadIdx.x & 63) == 0) { mx[0][threadIdx.x >> 6] = dev; mx[1][threadIdx.x >> 6] = gb; mx[2][threadIdx.x >> 6] = bb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[b * 2 + 0] = mean;
+    stats[b * 2 + 1] = rstd;
+    if (amax_out) {
+      const float d = fmaxf(fmaxf(mx[0][0], mx[0][1]), fmaxf(mx[0][2], mx[0][3]));
+      const float g = fmaxf(fmaxf(mx[1][0], mx[1][1]), fmaxf(mx[1][2], mx[1][3]));
+      const float bt = fmaxf(fmaxf(mx[2][0], mx[2][1]), fmaxf(mx[2][2], mx[2][3]));
+      atomic_amax(amax_out, g * d * rstd + bt);
+    }
+  }
 }
 
 // ---- backward ----------------------------------------------------------------------------------------
@@ -303,8 +347,8 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
 // ---- host ----------------------------------------------------------------------------------------------
 extern "C" size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C) {
   const LnGeom g = ln_geom(B, HW, C);
-  // fwd: part[B][G][3]; bwd: sspart[B][G][2] + chpart[B][G][3][C]
-  return ((size_t)B * g.G * 3 + (size_t)B * g.G * 2 + (size_t)B * g.G * 3 * C) * sizeof(float) + 256;
+  // fwd: part[B][G][SGG_TS]; bwd: sspart[B][G][2] + chpart[B][G][3][C]
+  return ((size_t)B * g.G * SGG_TS + (size_t)B * g.G * 2 + (size_t)B * g.G * 3 * C) * sizeof(float) + 256;
 }
 
 static int ln_check(const char* name, int B, int HW, int C, size_t ws_bytes, void* ws) {
@@ -317,7 +361,7 @@ static int ln_check(const char* name, int B, int HW, int C, size_t ws_bytes, voi
   return SGG_OK;
 }
 
-// tile_stats / n_tile_stats (optional): [B][n_tile_stats][3] (count, mean, M2) partials of y already produced by the
+// tile_stats / n_tile_stats (optional): [B][n_tile_stats][4] (count, mean, M2, max |y - mean|) partials of y already produced by the
 // convolution's epilogue (sgg_conv2d_nhwc_fwd); the statistics pass over y is then skipped.
 extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
                                          float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
@@ -341,6 +385,17 @@ extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, con
   return SGG_OK;
 }
 
+// Statistics without the apply pass, for consumers that normalise y on the fly (LN prologue of sgg_conv2d_nhwc_fwd / _wgrad):
+// stats[b] = (mean, rstd) from the convolution's tile partials, and amax_out max-ed with an upper bound of max|ELU(LN(y))|.
+extern "C" int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_stats, const float* gamma, const float* beta, float* stats,
+                                          float* amax_out, int B, int HW, int C, void* stream) {
+  SGG_CHECK_ARG(tile_stats && n_tile_stats > 0 && gamma && beta && stats && B > 0 && HW > 0 && C > 0, "sgg_layernorm_hwc_finalize: bad argument");
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tile_stats, n_tile_stats, (float)((long long)HW * C),
+                     gamma, beta, C, stats, amax_out);
+  SGG_LAUNCH_CHECK("sgg_layernorm_hwc_finalize");
+  return SGG_OK;
+}
+
 extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
                                          const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
                                          float* amax_out, int B, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
@@ -349,7 +404,7 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
   if (rc) return rc;
   const LnGeom g = ln_geom(B, HW, C);
   hipStream_t st = (hipStream_t)stream;
-  float* sspart = (float*)ws + (size_t)B * g.G * 3;
+  float* sspart = (float*)ws + (size_t)B * g.G * SGG_TS;
   float* chpart = sspart + (size_t)B * g.G * 2;
   hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart, g.N, C,
                      g.G, g.cpg);

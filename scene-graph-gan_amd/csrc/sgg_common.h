@@ -28,6 +28,10 @@ extern "C" void sgg_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// LayerNorm partial statistics of a tile of y, as the convolution epilogues emit them and the LayerNorm kernels merge them:
+// (count, mean, M2 = sum (y - mean)^2, max |y - mean|) -> SGG_TS floats per tile
+#define SGG_TS 4
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -89,6 +93,10 @@ typedef float sgg_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void f16_split2(float a, float b, unsigned& hi, unsigned& lo) {
   const sgg_h2 h = __builtin_convertvector(sgg_f2{a, b}, sgg_h2);
   hi = __builtin_bit_cast(unsigned, h);
+#ifdef SGG_EXPERIMENT_NOSPLIT      // timing experiment only (scripts/build_prof_lib.sh nosplit): what the staging costs without the residual piece
+  lo = hi;
+  return;
+#endif
   const sgg_h2 l = __builtin_convertvector(sgg_f2{a - (float)h[0], b - (float)h[1]}, sgg_h2);
   lo = __builtin_bit_cast(unsigned, l);
 }

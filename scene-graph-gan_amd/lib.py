@@ -32,14 +32,15 @@ SIGNATURES = {
     "sgg_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "sgg_conv_wsplit_layout": (_i, [_i] * 8),
     "sgg_conv_split_weights_frag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
     "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
-    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _sz, _vp]),
+    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
     "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 4 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -130,6 +131,10 @@ class HipKernels:
         #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance).
         self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
         self.conv_halo = os.environ.get("SGG_CONV_HALO", "1") != "0"
+        # SGG_LN_FUSION=1: LayerNorm + ELU applied by the consuming convolution's patch staging where the halo-resident kernels serve
+        # it (trunk.py), the activation is never written.  Built, parity-tested and MEASURED SLOWER on MI355X (60.2 vs 53.6 ms per step:
+        # the extra staging VALU / LDS work costs the matrix kernels more than the saved 2.6 ms of LayerNorm passes), so off by default.
+        self.ln_fusion = os.environ.get("SGG_LN_FUSION", "0") != "0"
         assert self.conv_precision in (0, 2, 3, 6)
         self._amax_by_stream = {}
 
@@ -244,30 +249,36 @@ class HipKernels:
         return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], k, k, stride, self.conv_precision,
                                                        layout)
 
-    def halo_symbol(self, n_out, n_in):
+    def halo_symbol(self, n_out, n_in, lnp=False):
         tile = "2,128,2,2" if n_out % 128 == 0 else ("4,64,4,1" if n_out % 64 == 0 else "4,32,4,1")
-        return "conv_halo3_kernel<%s,%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
-                                                   "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false", "true" if n_in == 32 else "false")
+        return "conv_halo3_kernel<%s,%s,%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
+                                                      "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false",
+                                                      "true" if n_in == 32 else "false", "true" if lnp else "false")
 
     def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True):
         """(csrc/conv_s2.hip: sgg_s2_launch picks 128-position bands when 224-position ones give at most 256 work items)"""
         mt = 4 if (not stats and -(-m_positions // 224) * (n_out // 128) <= 256) else 7
         return "conv_s2_kernel<%s,%s,%d>" % ("true" if dgrad else "false", "true" if self.conv_precision == 2 else "false", mt)
 
-    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0):
-        """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3)."""
+    def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0,
+                 ln=None):
+        """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3).
+        ln = (stats [B,2], gamma, beta): x is the producing layer's PRE-LayerNorm output; the kernel applies LN + ELU while staging
+        (halo-resident kernel only; amax_x = the word ln_finalize published)."""
         self._dev(x, w_fwd, bias, y)
+        ln_s, ln_g, ln_b = ln if ln is not None else (None, None, None)
+        self._dev(ln_s, ln_g, ln_b)
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3]) if w_split_layout == 1 else
+        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
                                                              self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
             _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, w_split_layout, _p(amax_x), _p(amax_w),
-            _p(tile_stats), self._stream())), "sgg_conv2d_nhwc_fwd")
+            _p(tile_stats), _p(ln_s), _p(ln_g), _p(ln_b), self._stream())), "sgg_conv2d_nhwc_fwd")
 
     def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None, w_split_layout=0):
         self._dev(dy, w_hwio, dx)
@@ -281,8 +292,11 @@ class HipKernels:
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),
             self._stream())), "sgg_conv2d_nhwc_dgrad")
 
-    def conv_wgrad(self, x, dy, dw, stride, amax_x=None, amax_dy=None):
+    def conv_wgrad(self, x, dy, dw, stride, amax_x=None, amax_dy=None, ln=None):
+        """ln: as conv_fwd (x = pre-LayerNorm output of the producing layer; halo-resident wgrad kernel only)."""
         self._dev(x, dy, dw)
+        ln_s, ln_g, ln_b = ln if ln is not None else (None, None, None)
+        self._dev(ln_s, ln_g, ln_b)
         d = self._conv_dims(x.shape, dw.shape, stride)
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous()
         need = self.lib.sgg_conv2d_nhwc_wgrad_workspace_bytes(*d[:9])
@@ -291,8 +305,8 @@ class HipKernels:
         if d[3] != 3:
             amax_x, amax_dy = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(dy, amax_dy, 1)
         self._check(self._timed("conv_wgrad(call: wgrad kernel + slab reduce)", flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
-            _p(x), _p(dy), _p(dw), *d, self.conv_precision, 0 if self.conv_halo else 1, _p(amax_x), _p(amax_dy), _p(ws), ws.numel(),
-            self._stream())),
+            _p(x), _p(dy), _p(dw), *d, self.conv_precision, 0 if self.conv_halo else 1, _p(amax_x), _p(amax_dy), _p(ln_s), _p(ln_g), _p(ln_b),
+            _p(ws), ws.numel(), self._stream())),
             "sgg_conv2d_nhwc_wgrad")
 
     def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None, tile_stats=None):
@@ -307,6 +321,20 @@ class HipKernels:
         self._check(self._timed("ln_elu_fwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_fwd(
             _p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), _p(tile_stats), nts, B, H * W, C, _p(ws), ws.numel(),
             self._stream()), nb), "sgg_layernorm_hwc_elu_fwd")
+
+    def ln_finalize(self, tile_stats, gamma, beta, stats, amax_out, hw):
+        """Statistics only: stats [B,2] = (mean, rstd) from the conv epilogue's tile partials [B,n,4]; amax_out (1 word, may be None)
+        is max-ed with an upper bound of max|ELU(LN(y))|.  For consumers with an LN prologue (conv_fwd / conv_wgrad ln=...)."""
+        self._dev(tile_stats, gamma, beta, stats, amax_out)
+        B, nts, _ = tile_stats.shape
+        self._check(self.lib.sgg_layernorm_hwc_finalize(_p(tile_stats), nts, _p(gamma), _p(beta), _p(stats), _p(amax_out), B, hw,
+                                                        gamma.shape[0], self._stream()), "sgg_layernorm_hwc_finalize")
+
+    def ln_prologue_ok(self, k, stride, H, W, cin, cout):
+        """True if conv_fwd AND conv_wgrad of this layer can apply the producing layer's LayerNorm + ELU themselves
+        (halo-resident 3x3 stride-1 kernels of the split modes; the C ABI rejects the prologue elsewhere)."""
+        return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
+                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) == 1)
 
     def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None):
         self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out)

@@ -52,7 +52,7 @@ class Trunk:
             if has_ln and hasattr(K, "conv_tile_stats_count"):
                 nts = K.conv_tile_stats_count((B, ho, wo, cout), cin, k, s, lay["ws_layout"])
                 if nts > 0:     # the conv epilogue emits the LayerNorm partial statistics for this shape
-                    lay["tstats"] = torch.zeros((B, nts, 3), device=dev, dtype=dt)
+                    lay["tstats"] = torch.zeros((B, nts, 4), device=dev, dtype=dt)
                     lay["tstats_mode"] = (K.conv_precision, lay["ws_layout"])
             if has_ln:
                 lay["gamma"], lay["beta"] = p[ln_name(i) + "/gamma"], p[ln_name(i) + "/beta"]
@@ -86,6 +86,21 @@ class Trunk:
     def _am(self, row, j):
         return self.amax[row, j:j + 1] if self._f16() else None
 
+    def _plan_ln_fusion(self):
+        """lay["fuse_ln"]: this layer's LayerNorm + ELU is applied by its consumer (the next convolution's forward and wgrad patch
+        staging) instead of a separate pass: the activation a_j is never written.  Needs the statistics partials from this layer's
+        conv epilogue and a consumer served by the halo-resident kernels in the conv precision in force."""
+        K = self.K
+        for j, lay in enumerate(self.layers):
+            lay["fuse_ln"] = False
+            if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and getattr(K, "ln_fusion", True)) or j + 1 >= len(self.layers):
+                continue
+            nxt = self.layers[j + 1]
+            stats_ok = lay["tstats"] is not None and (lay["cin"] == 3 or (lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision
+                                                                          and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])))
+            lay["fuse_ln"] = bool(stats_ok and nxt["ws_fwd"] is not None and
+                                  K.ln_prologue_ok(nxt["k"], nxt["s"], nxt["hin"], nxt["win"], nxt["cin"], nxt["cout"]))
+
     def refresh_weights(self):
         """Re-derive the HWOI forward layout after the parameters changed (Adam step / state-dict load)."""
         if self._f16():
@@ -100,6 +115,7 @@ class Trunk:
                     self.K.split_weights(lay["w_fwd"], lay["ws_fwd"], self._am(2, j), lay["ws_layout"])
                     self.K.split_weights(lay["w"], lay["ws_bwd"], self._am(2, j), lay["ws_layout_bwd"])
                     lay["ws_mode"] = self.K.conv_precision
+        self._plan_ln_fusion()
 
     def forward(self, images):
         """images [B,S,S,3] NHWC fp32, already standardised (train.py:172) -> downsampled as ctx [B, L, 512]."""
@@ -107,18 +123,31 @@ class Trunk:
         K = self.K
         self.images = images
         x = images
+        ln_in = None            # (stats, gamma, beta) when x is a pre-LayerNorm tensor whose LN + ELU this layer applies itself
         if self._f16():
             K.fill(self.amax[0], 0.0)
         for j, lay in enumerate(self.layers):
             ws = lay["ws_fwd"] if (lay["ws_fwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
             ts = lay["tstats"] if (lay["tstats"] is not None and (ws is not None or lay["cin"] == 3)
                                    and (lay["cin"] == 3 or lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"]))) else None
-            if ws is not None or self._f16() or ts is not None:
+            if ln_in is not None:
+                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1), self._am(2, j), ts,
+                           lay["ws_layout"], ln=ln_in)
+            elif ws is not None or self._f16() or ts is not None:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j), ts,
                            lay["ws_layout"] if ws is not None else 0)
             else:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
+            ln_in = None
             if lay["has_ln"]:
+                if lay.get("fuse_ln") and ts is not None:
+                    # statistics only; the consumer normalises y while it stages its patches (forward and wgrad)
+                    K.ln_finalize(ts, lay["gamma"], lay["beta"], lay["stats"], self._am(0, j), lay["out_shape"][1] * lay["out_shape"][2])
+                    ln_in = (lay["stats"], lay["gamma"], lay["beta"])
+                    x = lay["y"]
+                    lay["fused_now"] = True
+                    continue
+                lay["fused_now"] = False
                 if self._f16() or ts is not None:
                     K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], self._am(0, j), ts)
                 else:
@@ -139,11 +168,16 @@ class Trunk:
             K.absmax(dy, self._am(1, n - 1))
         for j in range(n - 1, -1, -1):
             lay = self.layers[j]
-            x_in = self.images if j == 0 else self.layers[j - 1]["a"]
-            if f16:
-                K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
+            prv = self.layers[j - 1] if j else None
+            if prv is not None and prv.get("fused_now"):
+                # the input activation was never written: the wgrad kernel applies LayerNorm + ELU to the producing layer's y
+                K.conv_wgrad(prv["y"], dy, lay["gw"], lay["s"], self._am(0, j - 1), self._am(1, j), ln=(prv["stats"], prv["gamma"], prv["beta"]))
             else:
-                K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
+                x_in = self.images if j == 0 else prv["a"]
+                if f16:
+                    K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
+                else:
+                    K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
             if not lay["has_ln"]:
                 # last conv: BiasAddGrad = column sums of dy (LN layers get theirs from ln_elu_bwd below)
                 K.colsum(dy.view(-1, lay["cout"]), lay["gb"], False)

@@ -410,7 +410,7 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
         # LayerNorm partial statistics from the halo epilogue
         nts = hip.conv_tile_stats_count((B, H, W, Co), Ci, 3, 1, 1)
         assert nts == (H * W // 64) * (Co // (64 if Co % 64 == 0 else 32))
-        ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+        ts = torch.full((B, nts, 4), float("nan"), device="cuda")
         y2 = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y2, 1, ws_f, tile_stats=ts, w_split_layout=1)
         assert torch.equal(y2, y)
@@ -433,7 +433,7 @@ def test_conv_c3_tile_stats(hip, ref, shape):
     xd, wd, bd = dev(x), dev(w), dev(b)
     nts = hip.conv_tile_stats_count((B, H, W, 32), 3, 3, 1, 0)
     assert nts == -(-H // 8) * -(-W // 32)
-    ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+    ts = torch.full((B, nts, 4), float("nan"), device="cuda")
     y = torch.full((B, H, W, 32), float("nan"), device="cuda")
     hip.conv_fwd(xd, wd, wd, bd, y, 1, tile_stats=ts)
     y_ref = torch.empty((B, H, W, 32), dtype=torch.float64)
@@ -474,7 +474,7 @@ def test_conv_epilogue_layernorm_stats(hip, ref, cout):
     hip.hwio_to_hwoi(wd, wf)
     nts = hip.conv_tile_stats_count((B, H, W, cout), Ci)
     assert nts > 0
-    ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+    ts = torch.full((B, nts, 4), float("nan"), device="cuda")
     y = torch.empty((B, H, W, cout), device="cuda")
     hip.conv_fwd(xd, wd, wf, bd, y, s, tile_stats=ts)
     a1, a2 = torch.empty_like(y), torch.empty_like(y)
@@ -546,7 +546,7 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
         nts = hip.conv_tile_stats_count((B, Ho, Ho, Co), Ci, 5, 2, 2)
         assert nts == ((Ho * Ho // 224) * (Co // 32) if (Ho * Ho) % 224 == 0 else 0)
         if nts:
-            ts = torch.full((B, nts, 3), float("nan"), device="cuda")
+            ts = torch.full((B, nts, 4), float("nan"), device="cuda")
             y2 = torch.empty_like(y)
             hip.conv_fwd(xd, wd, wf, bd, y2, 2, ws_f, tile_stats=ts, w_split_layout=2)
             assert torch.equal(y2, y)
@@ -557,5 +557,76 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
             hip.ln_elu_fwd(y, gamma, beta, a2, st2)
             close(st1, st2.cpu(), rtol=1e-6, what="stats from the s2 epilogue vs statistics pass")
             close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+    finally:
+        hip.conv_precision = old
+
+
+LNP_CASES = [(2, 16, 24, 32, 32), (3, 8, 16, 64, 64), (2, 24, 16, 64, 128), (3, 8, 8, 128, 128), (1, 16, 16, 128, 256), (2, 8, 8, 256, 256),
+             (2, 16, 16, 32, 64), (1, 8, 8, 512, 512)]
+
+
+@pytest.mark.parametrize("mode", [2, 3], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("case", LNP_CASES)
+def test_layernorm_prologue_fwd_wgrad(hip, ref, case, mode):
+    """LN prologue: the halo-resident forward / wgrad kernels fed with the producing layer's PRE-LayerNorm output y apply
+    ELU(LN(y)) while staging their patches (generator_with_attention.py:30..56) - against conv(ELU(LN(y))) in fp64 and against the
+    unfused HIP path; the statistics come from sgg_layernorm_hwc_finalize over tile partials."""
+    from tests import conv_ref64 as R64
+    B, H, W, Ci, Co = case
+    old = hip.conv_precision
+    hip.conv_precision = mode
+    try:
+        tol = {2: 2e-5, 3: 1e-4}[mode]
+        assert hip.ln_prologue_ok(3, 1, H, W, Ci, Co)
+        y0 = rnd((B, H, W, Ci), 31, 2.0) + 0.7
+        y0[0] *= 3.0                                       # samples with different statistics
+        gamma, beta = 1.0 + rnd((Ci,), 32, 0.3), rnd((Ci,), 33, 0.3)
+        w, b = rnd((3, 3, Ci, Co), 34, 1.0 / math.sqrt(9 * Ci)), rnd((Co,), 35, 0.1)
+        dy = rnd((B, H, W, Co), 36)
+        a_ref = torch.empty((B, H, W, Ci), dtype=torch.float64)
+        st_ref = torch.empty((B, 2), dtype=torch.float64)
+        ref.ln_elu_fwd(y0.double(), gamma.double(), beta.double(), a_ref, st_ref)
+        y_ref = R64.conv_fwd64(a_ref, w.double(), b.double(), 1)
+        dw_ref = R64.conv_wgrad64(a_ref, dy.double(), 3, 1)
+        y0d, gd, bd2, wd, bd, dyd = dev(y0), dev(gamma), dev(beta), dev(w), dev(b), dev(dy)
+        # tile partials (count, mean, M2, max |y - mean|) in the [B, n, 4] format the conv epilogues emit, four tiles per sample
+        nt = 4
+        flat = y0.reshape(B, nt, -1).double()
+        ts = torch.empty((B, nt, 4), dtype=torch.float64)
+        ts[:, :, 0] = flat.shape[2]
+        ts[:, :, 1] = flat.mean(dim=2)
+        ts[:, :, 2] = ((flat - flat.mean(dim=2, keepdim=True)) ** 2).sum(dim=2)
+        ts[:, :, 3] = (flat - flat.mean(dim=2, keepdim=True)).abs().amax(dim=2)
+        tsd = dev(ts.float())
+        stats = torch.full((B, 2), float("nan"), device="cuda")
+        am = torch.zeros(3, device="cuda")
+        hip.ln_finalize(tsd, gd, bd2, stats, am[0:1] if mode == 2 else None, H * W)
+        close(stats, st_ref, rtol=1e-5, what="finalize stats")
+        if mode == 2:
+            assert float(am[0]) >= float(a_ref.abs().max()) * (1 - 1e-6), "published amax must bound max|a|"
+            assert float(am[0]) <= 64 * float(a_ref.abs().max()) + 1.0, "bound uselessly loose"
+        hip.absmax(wd, am[1:2])
+        hip.absmax(dyd, am[2:3])
+        wf = torch.empty((3, 3, Co, Ci), device="cuda")
+        hip.hwio_to_hwoi(wd, wf)
+        ws_f = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+        hip.split_weights(wf, ws_f, am[1:2], layout=1)
+        ln = (stats, gd, bd2)
+        y = torch.full((B, H, W, Co), float("nan"), device="cuda")
+        hip.conv_fwd(y0d, wd, wf, bd, y, 1, ws_f, am[0:1], am[1:2], None, 1, ln=ln)
+        close(y, y_ref, rtol=tol, what="forward with LN prologue %s" % (case,))
+        dw = torch.full((3, 3, Ci, Co), float("nan"), device="cuda")
+        hip.conv_wgrad(y0d, dyd, dw, 1, am[0:1], am[2:3], ln=ln)
+        close(dw, dw_ref, rtol=tol, what="wgrad with LN prologue %s" % (case,))
+        # the unfused HIP path on the same data
+        a = torch.empty((B, H, W, Ci), device="cuda")
+        st2 = torch.empty((B, 2), device="cuda")
+        hip.ln_elu_fwd(y0d, gd, bd2, a, st2)
+        y_u = torch.empty_like(y)
+        hip.conv_fwd(a, wd, wf, bd, y_u, 1, ws_f, w_split_layout=1)
+        close(y, y_u.cpu(), rtol=5e-6, what="fused vs unfused forward")
+        dw_u = torch.empty_like(dw)
+        hip.conv_wgrad(a, dyd, dw_u, 1)
+        close(dw, dw_u.cpu(), rtol=5e-6, what="fused vs unfused wgrad")
     finally:
         hip.conv_precision = old
