@@ -844,7 +844,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     SGG_CHECK_ARG(!tile_stats || sgg_s2_stats_per_sample(Ho, Wo, Cout) > 0, "sgg_conv2d_nhwc_fwd: tile_stats need Ho*Wo %% 224 == 0 here");
     S2Params q;
     q.src = x; q.wfrag = w_split; q.bias = bias; q.out = y; q.amax_src = amax_x; q.amax_w = amax_w; q.tile_stats = tile_stats;
-    q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cin; q.N = Cout; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo + 2;
+    q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cin; q.N = Cout; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo;
     q.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
     sgg_s2_launch(q, 0, precision, st);
@@ -908,7 +908,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
                   "sgg_conv2d_nhwc_dgrad: tensor exceeds 2 GiB");
     S2Params q;
     q.src = dy; q.wfrag = w_split; q.bias = nullptr; q.out = dx; q.amax_src = amax_dy; q.amax_w = amax_w; q.tile_stats = nullptr;
-    q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cout; q.N = Cin; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo + 2;
+    q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cout; q.N = Cin; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo;
     q.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
     sgg_s2_launch(q, 1, precision, (hipStream_t)stream);

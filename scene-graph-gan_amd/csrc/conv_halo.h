@@ -62,7 +62,7 @@ struct S2Params {
   int C, N;               // contraction channels, output channels
   int M;                  // B * Ho * Wo
   int nbands;             // ceil(M / 224)
-  int pitch;              // Wo + 2: slots per patch row
+  int pitch;              // Wo: slots per patch row (no halo columns: edge lanes read a zero slot)
   unsigned src_bytes, w_bytes;
   int gx;                 // workgroups per XCD (set by sgg_s2_launch)
 };

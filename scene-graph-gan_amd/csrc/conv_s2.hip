@@ -22,12 +22,16 @@
 //     (112 accumulator registers); the four waves share the patch.
 // LDS image: plane[pp][slot][16 channels] = 32-B slots; the two 16-B halves of a slot are swapped when bit 3 of the slot
 // index is set, which makes the ds_read_b128 of 32 consecutive slots conflict free (lane groups of MI355X_MICROARCH.md, LDS).
+// Patch rows are stored WITHOUT halo columns (pitch = Wo), so the 32 positions of a row tile are 32 consecutive slots even
+// where the tile runs over the end of an image row (with a two-slot gap per row 42 % of the LDS cycles were bank conflicts,
+// SQ_LDS_BANK_CONFLICT); the lanes whose tap falls off the left / right image edge read a reserved all-zero slot instead.
 #include "split16.h"
 #include "conv_halo.h"
 #include <type_traits>
 
 #define S2_BAND 224                   // positions per band in the 7-tile variant (what LayerNorm partials are defined on)
 #define S2_MAXSLOTS 496               // 2 buffers x 2 planes x 496 x 32 B + the row tables stay inside 64 KB of static LDS
+#define S2_ZSLOT (S2_MAXSLOTS - 1)    // never part of a patch: staged as zeros (out-of-range loads), read by edge lanes
 #define S2_PLB (S2_MAXSLOTS * 32)      // bytes of one plane of one patch buffer
 #define S2_NPASS 4                     // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256
 #define S2_BN 128
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       const int lr = slot / p.pitch, lc = slot - lr * p.pitch;
       const int pg = pg_first + lr;
       const int b = pg / Hp;
-      const int a = pg - b * Hp - 1, c = lc - 1;
+      const int a = pg - b * Hp - 1, c = lc;
       const bool ok = (lr < nrows) & (b < p.B) & (a >= 0) & (a < p.Ho) & (c >= 0) & (c < p.Wo);
       const unsigned off = DGRAD ? (unsigned)((((b * p.Ho + a) * p.Wo + c) * p.C + half * 8) * 4)
                                  : (unsigned)((((b * 2 * p.Ho + 2 * a) * 2 * p.Wo + 2 * c) * p.C + half * 8) * 4);
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   int slot0[MT];          // patch slot of this lane's output position in row tile t (the centre of its 3x3 neighbourhood)
+  bool edge_l[MT], edge_r[MT];   // this lane's position is in the first / last column of its image row (lane masks)
   int cur = 0;               // patch buffer the current stage reads
   float bias_v = 0.f;
   if constexpr (!DGRAD) bias_v = p.bias ? p.bias[n0 + i] : 0.f;
@@ -180,13 +185,16 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   // A fragments go through a ring of three register sets: the fragments of row tile k+2 (of this tap or the next one) are
   // read from the resident patch while the MFMAs of tile k issue, so an LDS latency is exposed only at the start of a stage.
   u32x4 ra[3][P];
-  auto read_a = [&](auto ring_c, auto t_c, int shift) __attribute__((always_inline)) {
-    constexpr int ring = decltype(ring_c)::value, t = decltype(t_c)::value;
+  auto read_a = [&](auto ring_c, auto t_c, auto dx_c, int shift) __attribute__((always_inline)) {
+    constexpr int ring = decltype(ring_c)::value, t = decltype(t_c)::value, dxx = decltype(dx_c)::value;
     // (opaque to the optimiser: otherwise the 175 per-tap LDS addresses, invariant across the chunk loop, are hoisted and spilled)
     int sc = slot0[t];
     asm volatile("" : "+v"(sc));
     const int s = sc + shift;
-    const unsigned char* a_ptr = lds + cur * (P * S2_PLB) + s * 32 + ((h ^ ((s >> 3) & 1)) << 4);
+    int off = s * 32 + ((h ^ ((s >> 3) & 1)) << 4);
+    if constexpr (dxx == 0) off = edge_l[t] ? S2_ZSLOT * 32 : off;      // column -1 of the image: zero padding
+    if constexpr (dxx == 2) off = edge_r[t] ? S2_ZSLOT * 32 : off;      // column Wo
+    const unsigned char* a_ptr = lds + cur * (P * S2_PLB) + off;
     ra[ring][0] = *reinterpret_cast<const u32x4*>(a_ptr);
     ra[ring][1] = *reinterpret_cast<const u32x4*>(a_ptr + S2_PLB);
   };
@@ -210,8 +218,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       constexpr int ti = decltype(ti_c)::value;
       return (Axis<DGRAD>::shift(qy, ti / nx) - 1) * p.pitch + (Axis<DGRAD>::shift(qx, ti % nx) - 1);
     };
-    read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, tap_shift(std::integral_constant<int, 0>{}));
-    read_a(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, tap_shift(std::integral_constant<int, 0>{}));
+    constexpr int dx0 = Axis<DGRAD>::shift(qx, 0);
+    read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, dx0>{}, tap_shift(std::integral_constant<int, 0>{}));
+    read_a(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, dx0>{}, tap_shift(std::integral_constant<int, 0>{}));
     auto body = [&](auto ti_c) __attribute__((always_inline)) {
       constexpr int ti = decltype(ti_c)::value;
       constexpr int par = (par0 + ti) & 1;
@@ -229,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         constexpr int k = ti * MT + t;
         if constexpr (k + 2 < ntaps * MT) {
           constexpr int nti = (k + 2) / MT, nt2 = (k + 2) % MT;
-          read_a(std::integral_constant<int, (k + 2) % 3>{}, std::integral_constant<int, nt2>{}, tap_shift(std::integral_constant<int, nti>{}));
+          read_a(std::integral_constant<int, (k + 2) % 3>{}, std::integral_constant<int, nt2>{},
+                 std::integral_constant<int, Axis<DGRAD>::shift(qx, nti % nx)>{}, tap_shift(std::integral_constant<int, nti>{}));
         }
         mma_tile(std::integral_constant<int, k % 3>{}, t_c, std::integral_constant<int, par>{});
       };
@@ -336,7 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       const int pp = min(p0 + t * 32 + i, p.M - 1);
       const int g = pp / p.Wo, ox = pp - g * p.Wo;
       const int b = g / p.Ho, oy = g - b * p.Ho;
-      slot0[t] = (b * Hp + oy + 1 - pg_first) * p.pitch + ox + 1;
+      slot0[t] = (b * Hp + oy + 1 - pg_first) * p.pitch + ox;
+      edge_l[t] = ox == 0;
+      edge_r[t] = ox == p.Wo - 1;
     }
     // (the row table is read after at least one workgroup barrier: every stage ends with one)
     if constexpr (!DGRAD) {
@@ -396,7 +408,7 @@ int sgg_s2_applicable(int KH, int KW, int stride, int B, int Hi, int Wi, int C, 
         (precision == 2 || precision == 3)))
     return 0;
   const int Ho = Hi / 2, Wo = Wi / 2;
-  return s2_max_rows(Ho, Wo) * (Wo + 2) <= S2_MAXSLOTS;
+  return s2_max_rows(Ho, Wo) * Wo <= S2_ZSLOT;      // the patch (pitch Wo, no halo columns) must leave the zero slot free
 }
 
 int sgg_s2_stats_per_sample(int Ho, int Wo, int N) { return ((Ho * Wo) % S2_BAND == 0) ? (Ho * Wo / S2_BAND) * (N / 32) : 0; }

@@ -1,15 +1,14 @@
-"""Copy the judged summaries of one gpurun profile directory into profiles/ and derive the roofline `traffic` value.
-   python scripts/summarize_profiles.py gpurun_out/r01 r01"""
+"""Copy the judged summaries of one gpurun profile directory (scripts/gpu_round.sh <step> <tag>) into profiles/ and derive the
+roofline `traffic` values.   python scripts/summarize_profiles.py gpurun_out/r02 r02"""
 import csv, json, os, shutil, sys
 from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), os.path.join(dst, "%s_rocprofv3_kernel_stats.csv" % tag))
-for f in ("bench.json", "bench_under_rocprof.json", "pytest_gpu.log", "bench_precision0_native_f32_mfma.json",
-          "bench_precision3_bf16x3.json", "bench_precision6_bf16x6.json", "bench_critic_iters10.json", "configs45.log",
-          "dp_rehearsal.log"):
+if os.path.exists(os.path.join(src, "stats", "k_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), os.path.join(dst, "%s_rocprofv3_kernel_stats.csv" % tag))
+for f in ("bench.json", "bench_under_rocprof.json", "bench_config3.json", "bench_config4.json", "pytest_gpu.log"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
 
@@ -24,18 +23,18 @@ def per_kernel(path, counter):
     return acc
 
 
-fetch = per_kernel(os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
-write = per_kernel(os.path.join(src, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
-rows, traffic = [], {}
-for k in sorted(fetch, key=lambda k: -fetch[k][1]):
-    n, f = fetch[k]
-    w = write.get(k, [0, 0.0])[1]
-    # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
-    # bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
-    per_launch = (2.0 * f + w) * 1024.0 / max(n, 1)
-    rows.append({"kernel": k, "launches": n, "fetch_kib_raw_sum": f, "write_kib_sum": w, "hbm_bytes_per_launch_corrected": per_launch})
-    short = k.replace("void ", "").split("(")[0].replace(" ", "")
-    traffic[short] = per_launch
-json.dump(rows, open(os.path.join(dst, "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
-json.dump(traffic, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
-print("wrote", os.listdir(dst))
+fpath, wpath = os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), os.path.join(src, "pmc_write", "w_counter_collection.csv")
+if os.path.exists(fpath) and os.path.exists(wpath):
+    fetch, write = per_kernel(fpath, "FETCH_SIZE"), per_kernel(wpath, "WRITE_SIZE")
+    rows, traffic = [], {}
+    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+        n, f = fetch[k]
+        w = write.get(k, [0, 0.0])[1]
+        # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
+        # bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+        per_launch = (2.0 * f + w) * 1024.0 / max(n, 1)
+        rows.append({"kernel": k, "launches": n, "fetch_kib_raw_sum": f, "write_kib_sum": w, "hbm_bytes_per_launch_corrected": per_launch})
+        traffic[k.replace("void ", "").split("(")[0].replace(" ", "")] = per_launch
+    json.dump(rows, open(os.path.join(dst, "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag) or f == "roofline_traffic.json"))
