@@ -170,6 +170,13 @@ int sgg_wgan_gp_loss_bwd(const float* g, const float* slopes, const float* pen, 
 /* out4 = { disc_cost, wasserstein distance term, gradient penalty, mean D(fake) }  (gen_cost = -out4[3]) */
 int sgg_wgan_losses(const float* d_out, const float* pen, float lam, int B, int T, int has_real, float* out4, void* stream);
 
+/* ---- input pipeline: tf.image.resize_images(decoded, [221, 221]) + standardisation: train.py:171-172 ---------------------
+ * TF 1.x bilinear resize with its defaults (align_corners=False: legacy grid src = dst * in/out, no antialiasing) of B RGB
+ * uint8 images of different sizes ([H_b][W_b][3] at src + offsets[b], device memory) into dst [B][out_h][out_w][3] fp32,
+ * then (x - means[c]) / stds[c]. */
+int sgg_resize_bilinear_tf1(const unsigned char* src, const long long* offsets, const int* heights, const int* widths, float* dst,
+                            int B, int out_h, int out_w, const float* means, const float* stds, void* stream);
+
 /* ---- tf.train.AdamOptimizer(1e-4, beta1=0.5, beta2=0.9).minimize: train.py:258-266 ---------------------------
  * lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is computed by the caller; theta -= lr_t*m/(sqrt(v)+eps). */
 int sgg_adam_tf_multi(float* params, const float* grads, float* m, float* v, long long n, float lr_t, float beta1,

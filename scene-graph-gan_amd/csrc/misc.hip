@@ -229,6 +229,34 @@ extern "C" int sgg_interpolate(const float* real, const float* fake, const float
   return SGG_OK;
 }
 
+// tf.image.resize_images(image, [oh, ow]) of TF 1.x (bilinear, align_corners=False: the LEGACY grid src = dst * in/out, no half-pixel
+// offset, no antialiasing) followed by (x - mean) / std: train.py:171-172.  One launch per batch: image b is RGB uint8 [H_b][W_b][3]
+// at src + offsets[b] (variable sizes, packed by the host loader); dst [B][oh][ow][3] fp32.  Arithmetic order as TF's kernel
+// (top / bottom row interpolated in x, then in y; no fused multiply-add: equals the host restatement within a few ulps).
+__global__ void resize_bilinear_tf1_kernel(const unsigned char* __restrict__ src, const long long* __restrict__ offsets,
+                                           const int* __restrict__ heights, const int* __restrict__ widths, float* __restrict__ dst,
+                                           int oh, int ow, const float* __restrict__ means, const float* __restrict__ stds) {
+  const int b = blockIdx.y, y = blockIdx.x;
+  const int H = heights[b], W = widths[b];
+  const unsigned char* im = src + offsets[b];
+  const float sy = __fdiv_rn((float)H, (float)oh), sx = __fdiv_rn((float)W, (float)ow);
+  const float fy = __fmul_rn((float)y, sy);
+  const int y0 = (int)floorf(fy), y1 = min(y0 + 1, H - 1);
+  const float wy = __fsub_rn(fy, (float)y0);
+  for (int i = threadIdx.x; i < ow * 3; i += blockDim.x) {
+    const int x = i / 3, c = i - 3 * x;
+    const float fx = __fmul_rn((float)x, sx);
+    const int x0 = (int)floorf(fx), x1 = min(x0 + 1, W - 1);
+    const float wx = __fsub_rn(fx, (float)x0);
+    const float tl = (float)im[((size_t)y0 * W + x0) * 3 + c], tr = (float)im[((size_t)y0 * W + x1) * 3 + c];
+    const float bl = (float)im[((size_t)y1 * W + x0) * 3 + c], br = (float)im[((size_t)y1 * W + x1) * 3 + c];
+    const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), wx));
+    const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), wx));
+    const float v = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), wy));
+    dst[(((size_t)b * oh + y) * ow + x) * 3 + c] = __fdiv_rn(__fsub_rn(v, means[c]), stds[c]);
+  }
+}
+
 extern "C" int sgg_onehot(const long long* labels, float* out, int rows, int V, void* stream) {
   SGG_CHECK_ARG(labels && out && rows > 0 && V > 0, "sgg_onehot: bad argument");
   hipLaunchKernelGGL(onehot_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, labels, out, V);
@@ -251,6 +279,16 @@ extern "C" int sgg_embed_gather_bwd(const long long* labels, int label_stride, c
   hipLaunchKernelGGL(embed_gather_bwd_kernel, dim3(R), dim3(128), (size_t)R * sizeof(long long), (hipStream_t)stream, labels,
                      label_stride, dY, lddy, dW, V, E, R);
   SGG_LAUNCH_CHECK("sgg_embed_gather_bwd");
+  return SGG_OK;
+}
+
+extern "C" int sgg_resize_bilinear_tf1(const unsigned char* src, const long long* offsets, const int* heights, const int* widths,
+                                       float* dst, int B, int out_h, int out_w, const float* means, const float* stds, void* stream) {
+  SGG_CHECK_ARG(src && offsets && heights && widths && dst && means && stds && B > 0 && out_h > 0 && out_w > 0,
+                "sgg_resize_bilinear_tf1: bad argument");
+  hipLaunchKernelGGL(resize_bilinear_tf1_kernel, dim3(out_h, B), dim3(256), 0, (hipStream_t)stream, src, offsets, heights, widths, dst,
+                     out_h, out_w, means, stds);
+  SGG_LAUNCH_CHECK("sgg_resize_bilinear_tf1");
   return SGG_OK;
 }
 

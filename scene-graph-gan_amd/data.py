@@ -55,24 +55,54 @@ def parse_image(path, means, stds, side=IMAGE_SIDE):
     return (x - np.asarray(means, dtype=np.float32)) / np.asarray(stds, dtype=np.float32)
 
 
+def decode_rgb(path):
+    """tf.image.decode_jpeg(channels=3) (train.py:169): uint8 [H, W, 3]."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB")))
+
+
+def _parse_task(task):
+    """Worker-process entry point: (path, means, stds, side) -> float32 [side, side, 3]."""
+    path, means, stds, side = task
+    return parse_image(path, means, stds, side)
+
+
 class PrefetchLoader:
     """Batches of (images [B, side, side, 3] float32, labels [B, 3] int64) on `device`, produced ahead of the consumer.
 
-    Worker threads decode / resize / standardise single images (PIL and NumPy release the GIL in their inner loops); a
-    producer thread assembles each batch into one of `depth` pinned host buffers and issues the host-to-device copy on its
-    own HIP stream, so batch k+1 is decoded and copied while batch k trains.  `index_fn(it)` gives the example indices of
-    iteration `it` (the trainer's shard of the shuffled file list); iteration order is deterministic."""
+    On a HIP device (the product path): worker threads only DECODE (libjpeg releases the GIL); the producer thread packs the
+    batch's uint8 images back to back into one of `depth` pinned host buffers, copies them to the device on its own HIP stream
+    and launches ONE resize + standardise kernel for the whole batch there (sgg_resize_bilinear_tf1: the TF-1.x arithmetic,
+    equal to `resize_bilinear_tf1` within a few ulps), so batch k+1 is decoded, copied and resized while batch k trains.
+    On the CPU (tests; `processes=True` uses spawned worker processes instead of threads) the workers run `parse_image`.
+    `index_fn(it)` gives the example indices of iteration `it` (the trainer's shard of the shuffled file list); iteration
+    order is deterministic."""
 
     def __init__(self, files, labels, batch_size, index_fn, means, stds, device, num_iterations, start=0, workers=16, depth=2,
-                 side=IMAGE_SIDE):
+                 side=IMAGE_SIDE, processes=False):
         self.files, self.labels = files, np.asarray(labels, dtype=np.int64)
         self.B, self.index_fn, self.means, self.stds, self.side = batch_size, index_fn, means, stds, side
         self.device = torch.device(device)
         self.start, self.stop = start, num_iterations
-        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.processes = processes and self.device.type != "cuda"      # on a HIP device the workers only decode: threads
+        if self.processes:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            self.pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"))
+        else:
+            self.pool = ThreadPoolExecutor(max_workers=workers)
         self.depth = depth
         pin = self.device.type == "cuda"
-        self.host = [torch.empty((batch_size, side, side, 3), dtype=torch.float32, pin_memory=pin) for _ in range(depth)]
+        self.K = None
+        if pin:
+            from .lib import HipKernels
+            self.K = HipKernels(self.device)
+            self.packed = [torch.empty(batch_size * 640 * 480 * 3, dtype=torch.uint8, pin_memory=True) for _ in range(depth)]
+            self.meta = [torch.empty(batch_size * 2, dtype=torch.int64, pin_memory=True) for _ in range(depth)]   # offsets | (h, w) pairs
+            self.d_means = torch.tensor(np.asarray(means, np.float32), device=self.device)
+            self.d_stds = torch.tensor(np.asarray(stds, np.float32), device=self.device)
+        self.host = [torch.empty((batch_size, side, side, 3), dtype=torch.float32) for _ in range(depth if not pin else 0)]
         self.free = queue.Queue()
         for i in range(depth):
             self.free.put(i)
@@ -90,8 +120,17 @@ class PrefetchLoader:
             for it in range(self.start, self.stop):
                 idx = self.index_fn(it)
                 slot = self.free.get()
+                if self.K is not None:
+                    self.ready.put(self._produce_device(slot, idx))
+                    continue
                 buf = self.host[slot]
-                list(self.pool.map(lambda jp: self._fill(buf, jp[0], self.files[jp[1]]), enumerate(idx)))
+                if self.processes:
+                    means, stds = np.asarray(self.means, np.float32), np.asarray(self.stds, np.float32)
+                    tasks = [(self.files[i], means, stds, self.side) for i in idx]
+                    for j, arr in enumerate(self.pool.map(_parse_task, tasks, chunksize=max(1, len(tasks) // 64))):
+                        buf[j] = torch.from_numpy(arr)
+                else:
+                    list(self.pool.map(lambda jp: self._fill(buf, jp[0], self.files[jp[1]]), enumerate(idx)))
                 labels = torch.from_numpy(self.labels[idx])
                 if self.copy_stream is not None:
                     with torch.cuda.stream(self.copy_stream):
@@ -106,6 +145,38 @@ class PrefetchLoader:
             self.error = e
         finally:
             self.ready.put(None)
+
+    def _produce_device(self, slot, idx):
+        """Decode on worker threads, pack, one host-to-device copy, one resize + standardise launch (copy stream)."""
+        rgbs = list(self.pool.map(lambda i: decode_rgb(self.files[i]), idx))
+        sizes = [a.size for a in rgbs]
+        total = int(sum(sizes))
+        if self.packed[slot].numel() < total:
+            self.packed[slot] = torch.empty(int(total * 1.25), dtype=torch.uint8, pin_memory=True)
+        packed, meta = self.packed[slot], self.meta[slot]
+        pk = packed.numpy()
+        off = 0
+        hw = np.empty((len(rgbs), 2), np.int32)
+        offs = np.empty(len(rgbs), np.int64)
+        for j, a in enumerate(rgbs):
+            pk[off:off + a.size] = a.reshape(-1)
+            offs[j] = off
+            hw[j] = a.shape[:2]
+            off += a.size
+        meta.numpy()[:len(rgbs)] = offs
+        hw_t = torch.from_numpy(hw)
+        labels = torch.from_numpy(self.labels[idx])
+        with torch.cuda.stream(self.copy_stream):
+            d_packed = packed[:total].to(self.device, non_blocking=True)
+            d_offs = meta[:len(rgbs)].to(self.device, non_blocking=True)
+            d_hw = hw_t.pin_memory().to(self.device, non_blocking=True)
+            dev_labels = labels.pin_memory().to(self.device, non_blocking=True)
+            dev_images = torch.empty((len(rgbs), self.side, self.side, 3), dtype=torch.float32, device=self.device)
+            d_h, d_w = d_hw[:, 0].contiguous(), d_hw[:, 1].contiguous()
+            self.K.resize_bilinear_tf1(d_packed, d_offs, d_h, d_w, dev_images, self.d_means, self.d_stds)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        return (slot, dev_images, dev_labels, done)
 
     def __iter__(self):
         return self

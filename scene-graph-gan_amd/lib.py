@@ -57,6 +57,7 @@ SIGNATURES = {
     "sgg_colsum_workspace_bytes": (_sz, [_i, _i]),
     "sgg_colsum": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "sgg_onehot": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sgg_resize_bilinear_tf1": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sgg_embed_gather_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "sgg_embed_gather_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sgg_interpolate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -530,6 +531,15 @@ class HipKernels:
         R = labels.shape[0]
         self._check(self.lib.sgg_embed_gather_bwd(_p(labels), max(labels.stride(0), 1), _p(dY), _ld(dY), _p(dW), V, E, R,
                                                   self._stream()), "sgg_embed_gather_bwd")
+
+    def resize_bilinear_tf1(self, packed, offsets, heights, widths, out, means, stds):
+        """packed uint8 [nbytes] (RGB images back to back), offsets int64 [B], heights / widths int32 [B] -> out [B,oh,ow,3] fp32 =
+        (tf.image.resize_images(img, [oh, ow]) - means) / stds  (train.py:171-172)."""
+        self._dev(packed, offsets, heights, widths, out, means, stds)
+        assert packed.dtype == torch.uint8 and offsets.dtype == torch.int64 and heights.dtype == torch.int32 and widths.dtype == torch.int32
+        B, oh, ow, _ = out.shape
+        self._check(self.lib.sgg_resize_bilinear_tf1(_p(packed), _p(offsets), _p(heights), _p(widths), _p(out), B, oh, ow, _p(means),
+                                                     _p(stds), self._stream()), "sgg_resize_bilinear_tf1")
 
     def interpolate(self, real, fake, alpha, out):
         self._dev(real, fake, alpha, out)

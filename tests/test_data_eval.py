@@ -86,6 +86,20 @@ def test_prefetch_loader_equals_synchronous_pipeline(tmp_path):
     assert x.shape == (221, 221, 3) and np.isfinite(x).all()
 
 
+def test_prefetch_loader_with_worker_processes(tmp_path):
+    files = _write_jpegs(tmp_path, 6)
+    labels = np.arange(18).reshape(6, 3)
+    means, stds = np.array([120.0, 115.0, 100.0], np.float32), np.array([60.0, 58.0, 61.0], np.float32)
+    loader = D.PrefetchLoader(files, labels, 3, lambda it: [(2 * it + j) % 6 for j in range(3)], means, stds, "cpu", 2, workers=2, side=17,
+                              processes=True)
+    got = list(loader)
+    assert len(got) == 2
+    for k, (images, labs) in enumerate(got):
+        idx = [(2 * k + j) % 6 for j in range(3)]
+        assert np.array_equal(images.numpy(), np.stack([D.parse_image(files[i], means, stds, 17) for i in idx]))
+        assert np.array_equal(labs.numpy(), labels[idx])
+
+
 def test_prefetch_loader_surfaces_decode_errors(tmp_path):
     files = _write_jpegs(tmp_path, 4) + [os.path.join(str(tmp_path), "missing.jpg")]
     loader = D.PrefetchLoader(files, np.zeros((5, 3), np.int64), 5, lambda it: list(range(5)), [0, 0, 0], [1, 1, 1], "cpu", 1, workers=2, side=8)

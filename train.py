@@ -139,7 +139,7 @@ class SceneGraphGAN(object):
         host-to-device copy runs on its own stream while the previous batch trains."""
         files, labs = self.dataset["train"]
         return PrefetchLoader(files, labs, self.BATCH_SIZE, self._batch_indices, self.image_means.numpy(), self.image_stds.numpy(),
-                              self.device, stop, start=start, workers=workers)
+                              self.device, stop, start=start, workers=workers, processes=workers > 2)
 
     ############################################################
     ## Saving
