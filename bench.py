@@ -16,6 +16,7 @@ gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed reg
                         in the launch-bound head would cost about 1 % of the headline)
   native_f32            the same workload re-timed in the same run with native f32 MFMA arithmetic (mode 0)
   parity                same-run checks: default mode vs native f32 (logits, tokens) and both vs the CPU oracle
+  critic_iters_10       secondary line: the loop body with the reference flag's nominal CRITIC_ITERS = 10 (train.py:408)
   cpu_baseline          the CPU oracle timed on this box's host cores (same run, N = 1 only)
   rccl                  (N > 1) what the collective layer saw and how much of the all-reduce is exposed
 """
@@ -206,6 +207,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the cpu_baseline / oracle-parity step (0 = skip; default: the "
                                                                "whole per-GPU batch up to 224x224, 16 rows at 448x448)")
     ap.add_argument("--f32-steps", type=int, default=3, help="steps of the native-f32 leg (0 = skip)")
+    ap.add_argument("--ci10-steps", type=int, default=2, help="iterations of the critic_iters = 10 secondary leg (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="add per-layer conv timings to the JSON line")
     ap.add_argument("--overlap-streams", action="store_true", help="run the two encoders' forwards on two HIP streams (+3 %%)")
@@ -354,6 +356,30 @@ def main():
                 "max_logit_err": float((logits_main - logits_f32).abs().max()), "max_abs_logit": float(logits_f32.abs().max()),
                 "tokens_equal": bool(torch.equal(toks_main, toks_f32)), "top2_logit_margin": O.top2_margin(logits_f32.cpu()),
                 "on": "generator logits [%d,3,%d] of the timed workload after the timed steps, same weights" % (B, V)}}
+
+    # ---- secondary line: the reference flag's nominal CRITIC_ITERS = 10 (train.py:408): 10 critic updates + 1 generator update -----
+    if CI == 1 and args.ci10_steps > 0:
+        def iteration10(j):
+            for i in range(10):
+                gs.critic_step(images, labels, noises[(j + i) % len(noises)], alphas[(j + i) % len(alphas)])
+            gs.generator_step(images, noises[(j + 10) % len(noises)])
+        iteration10(0)
+        gs.flush()
+        barrier()
+        t0 = time.perf_counter()
+        for j in range(args.ci10_steps):
+            iteration10(j + 1)
+        gs.flush()
+        barrier()
+        dt10 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt10], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt10 = float(t.item())
+        if rank == 0:
+            out["critic_iters_10"] = {"value": B * world * args.ci10_steps / dt10, "unit": "triples/sec (one iteration = 10 critic updates + 1 "
+                                      "generator update on one minibatch)", "iterations": args.ci10_steps,
+                                      "ms_per_iteration": 1e3 * dt10 / args.ci10_steps}
 
     if rank == 0:
         rows = args.cpu_rows if args.cpu_rows is not None else (B if S <= 224 else min(B, 16))
