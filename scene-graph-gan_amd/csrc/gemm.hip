@@ -135,6 +135,11 @@ __global__ void gemm_slab_reduce_kernel(const float* __restrict__ slabs, float* 
   *c = s;
 }
 
+// smallest K range one workgroup of a split-K head GEMM takes.  These GEMMs are chains of dependent 32-deep slabs (f32 MFMA: 0.43 us
+// per slab per wave) on a handful of tiles: deeper splits shorten the chain (measured 256 -> 64: 53.16 -> 52.82 ms per G+D step)
+#ifndef SGG_GEMM_MIN_KCHUNK
+#define SGG_GEMM_MIN_KCHUNK 64
+#endif
 static void gemm_plan(int M, int N, int K, int* nsplit, int* kchunk) {
   const int tiles = sgg_cdiv(M, 64) * sgg_cdiv(N, 64);
   int ns = 1;
@@ -147,8 +152,12 @@ static void gemm_plan(int M, int N, int K, int* nsplit, int* kchunk) {
     // the LSTM gate / decoder GEMMs (M = 64..384 rows, K = 512..1536): 32..96 tiles on 256 CUs, weight-streaming bound
     // (measured on one box, same call: 56.97 -> 55.9 ms per G+D step)
     ns = (256 + tiles - 1) / tiles;
-    const int maxns = K / 256;
+    const int maxns = K / SGG_GEMM_MIN_KCHUNK;
     if (ns > maxns) ns = maxns;
+    if (ns < 1) ns = 1;
+  } else if (tiles < 64 && K >= 128) {
+    ns = K / SGG_GEMM_MIN_KCHUNK;
+    if (ns > 64 / tiles) ns = 64 / tiles;
     if (ns < 1) ns = 1;
   }
   int kc = ((K + ns - 1) / ns + 31) / 32 * 32;
