@@ -35,6 +35,9 @@
 #define S2_PLB (S2_MAXSLOTS * 32)      // bytes of one plane of one patch buffer
 #define S2_NPASS 4                     // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256
 #define S2_BN 128
+#ifndef S2_SWZ
+#define S2_SWZ(slot) (((slot) >> 3) & 1)      // which 16-B half of a slot holds channels 0..7
+#endif
 
 namespace {
 
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
       if (tid + 256 * j < 2 * S2_MAXSLOTS) {
         const int slot = (tid + 256 * j) >> 1;
-        const int lds_off = slot * 32 + (((tid & 1) ^ ((slot >> 3) & 1)) << 4);
+        const int lds_off = slot * 32 + (((tid & 1) ^ S2_SWZ(slot)) << 4);
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * S2_PLB + lds_off) = pl[pp];
       }
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     int sc = slot0[t];
     asm volatile("" : "+v"(sc));
     const int s = sc + shift;
-    int off = s * 32 + ((h ^ ((s >> 3) & 1)) << 4);
+    int off = s * 32 + ((h ^ S2_SWZ(s)) << 4);
     if constexpr (dxx == 0) off = edge_l[t] ? S2_ZSLOT * 32 : off;      // column -1 of the image: zero padding
     if constexpr (dxx == 2) off = edge_r[t] ? S2_ZSLOT * 32 : off;      // column Wo
     const unsigned char* a_ptr = lds + cur * (P * S2_PLB) + off;
