@@ -564,14 +564,23 @@ __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) voi
 __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ tile_stats, int H, int W, int pt, int pl,
-                                                          int tiles_x, int tiles_y) {
+                                                          int tiles_x, int tiles_y, int ntiles) {
   constexpr int COUT = 32;
   __shared__ __attribute__((aligned(16))) f32x4 patch[10 * 34];
   __shared__ float red[12];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx = blockIdx.x % tiles_x, t2 = blockIdx.x / tiles_x;
+  const int sub = tid & 7, col = tid >> 3;
+  // the 27 x 4 weights of this thread's output channels stay in registers for every tile the workgroup walks (one workgroup per
+  // tile re-read 110 KB of weights per 32 KB of output)
+  f32x4 wv[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w + k * COUT + sub * 4);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + sub * 4);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int tx = tile % tiles_x, t2 = tile / tiles_x;
   const int ty = t2 % tiles_y, b = t2 / tiles_y;
   const int y0 = ty * 8, x0 = tx * 32;
+  __syncthreads();            // the previous tile's patch / reduction scratch are free
   for (int idx = tid; idx < 10 * 34; idx += 256) {
     const int r = idx / 34, c = idx % 34;
     const int yy = y0 - pt + r, xx = x0 - pl + c;
@@ -582,11 +591,6 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restric
     }
     patch[idx] = v;
   }
-  const int sub = tid & 7, col = tid >> 3;
-  f32x4 wv[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w + k * COUT + sub * 4);
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + sub * 4);
   __syncthreads();
 
   f32x4 rows[3][3];
@@ -640,6 +644,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restric
       o[2] = red[4] + red[5] + red[6] + red[7];
       o[3] = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
     }
+  }
   }
 }
 
@@ -815,8 +820,9 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
   if (Cin == 3) {
     SGG_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && Cout == 32, "sgg_conv2d_nhwc_fwd: Cin=3 path needs 3x3 s1 Cout=32");
     const int tiles_x = sgg_cdiv(Wo, 32), tiles_y = sgg_cdiv(Ho, 8);
-    hipLaunchKernelGGL(conv_c3_fwd_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), 0, st, x, w, bias, y, tile_stats, Hi, Wi,
-                       pad_t, pad_l, tiles_x, tiles_y);
+    const int ntiles = B * tiles_x * tiles_y;
+    hipLaunchKernelGGL(conv_c3_fwd_kernel, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(256), 0, st, x, w, bias, y, tile_stats,
+                       Hi, Wi, pad_t, pad_l, tiles_x, tiles_y, ntiles);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(c3)");
     return SGG_OK;
   }
