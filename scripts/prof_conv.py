@@ -30,9 +30,17 @@ if mode == "dgrad_ws": K.split_weights(w, ws, am[1:2], lay_b)
 ws0 = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
 if mode == "fwd_gather_ws": K.split_weights(wf, ws0, am[1:2], 0)
 if mode == "dgrad_gather_ws": K.split_weights(w, ws0, am[1:2], 0)
+ln = None
+if mode.endswith("_ln"):        # LN prologue timing: identity statistics (mean 0, rstd 1), gamma 1, beta 0 -> the staging applies ELU(x)
+    stats = torch.zeros((B, 2), device="cuda"); stats[:, 1] = 1.0
+    ln = (stats, torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda"))
+    K.split_weights(wf, ws, am[1:2], lay)
 def run():
     if mode == "fwd": K.conv_fwd(x, w, wf, b, y, s)
     elif mode == "fwd_ws": K.conv_fwd(x, w, wf, b, y, s, ws, am[0:1], am[1:2], None, lay)
+    elif mode == "fwd_ws_ln": K.conv_fwd(x, w, wf, b, y, s, ws, am[0:1], am[1:2], None, lay, ln=ln)
+    elif mode == "wgrad_ln": K.conv_wgrad(x, dy, dw, s, am[0:1], amdy, ln=ln)
+    elif mode == "wgrad": K.conv_wgrad(x, dy, dw, s, am[0:1], amdy)
     elif mode == "dgrad": K.conv_dgrad(dy, w, dx, s)
     elif mode == "dgrad_ws": K.conv_dgrad(dy, w, dx, s, ws, amdy, am[1:2], lay_b)
     elif mode == "fwd_gather_ws":
