@@ -1,0 +1,59 @@
+"""CPU: the parts of bench.py that do not need a GPU - the workload naming (BASELINE.json configs), the algorithmic FLOP
+accounting of SURVEY.md 8d and the record builders - so that the driver-facing JSON contract cannot drift silently."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_workload_names_follow_the_arguments():
+    assert bench.workload_name(64, 224, 1000, 1).startswith("BASELINE.json configs[1]")
+    assert bench.workload_name(64, 224, 70000, 1).startswith("BASELINE.json configs[3]")
+    assert bench.workload_name(32, 448, 1000, 1).startswith("BASELINE.json configs[4]")
+    assert bench.workload_name(8, 64, 50, 1).startswith("custom")           # the rehearsal size is NOT configs[1]
+    assert "10 critic updates" in bench.workload_name(64, 224, 1000, 10)
+    cfgs = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    assert "batch 64" in cfgs[1] and "448" in cfgs[4] and "70k" in cfgs[3]
+
+
+def test_conv_flops_per_step_matches_the_survey():
+    # 8*F_fwd - 2*f1 = 12 489.5 GFLOP at configs[1], 127.4 at configs[0], 24 979 at configs[4]
+    assert abs(bench.conv_flops_per_step(64, 224) / 1e9 - 12489.5) < 1.0
+    assert abs(bench.conv_flops_per_step(8, 64) / 1e9 - 127.4) < 0.1
+    assert abs(bench.conv_flops_per_step(32, 448) / 1e9 - 24979.0) < 2.0
+
+
+class _Ev:
+    def __init__(self, t):
+        self.t = t
+
+    def elapsed_time(self, other):
+        return other.t - self.t
+
+
+def test_roofline_records_from_event_timings():
+    timing = [("conv_halo3_kernel<2,128,2,2,true,true,false,false>", 236.8e9, 0.0, _Ev(0.0), _Ev(0.6)),
+              ("conv_halo3_kernel<2,128,2,2,true,true,false,false>", 236.8e9, 0.0, _Ev(1.0), _Ev(1.6)),
+              ("conv_s2_kernel<false,true,7>", 328.8e9, 0.0, _Ev(2.0), _Ev(2.9)),
+              ("adam_kernel", 0.0, 967e6, _Ev(3.0), _Ev(3.16))]
+    per = bench.summarise_timing(timing)
+    r = bench.conv_roofline(per, 2, dt=0.01)
+    assert r["kernel"].startswith("conv_halo3_kernel") and r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert abs(r["achieved"] - 2 * 236.8e9 / 1.2e-3 / 1e12) < 1e-6 and abs(r["peak"] - 2500.0 / 3) < 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches"] == 2
+    f32 = bench.conv_roofline(per, 0, dt=0.01)
+    assert f32["peak"] == 157.3
+    hbm = bench.hbm_rooflines(per, steps=1)
+    assert [h["kernel"] for h in hbm] == ["adam_kernel"]
+    assert abs(hbm[0]["GBps"] - 967e6 / 0.16e-3 / 1e9) < 1e-6 and abs(hbm[0]["frac_of_8TBps"] - hbm[0]["GBps"] / 8000.0) < 1e-12
+
+
+def test_cli_contract_flags_exist():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--critic-iters", "--cpu-rows", "--f32-steps"):
+        assert flag in out.stdout
