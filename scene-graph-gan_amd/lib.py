@@ -132,10 +132,12 @@ class HipKernels:
         #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance).
         self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
         self.conv_halo = os.environ.get("SGG_CONV_HALO", "1") != "0"
-        # SGG_LN_FUSION=1: LayerNorm + ELU applied by the consuming convolution's patch staging where the halo-resident kernels serve
-        # it (trunk.py), the activation is never written.  Built, parity-tested and MEASURED SLOWER on MI355X (60.2 vs 53.6 ms per step:
-        # the extra staging VALU / LDS work costs the matrix kernels more than the saved 2.6 ms of LayerNorm passes), so off by default.
-        self.ln_fusion = os.environ.get("SGG_LN_FUSION", "0") != "0"
+        # LayerNorm + ELU applied by the consuming 3x3 convolution's patch staging (trunk.py), the activation is never written:
+        #   0 (default): off - every LayerNorm is a pass of its own (statistics from the producing conv's epilogue);
+        #   1          : only in encoder forwards that no backward follows (G in the critic update, D in the generator update) and
+        #                for consumers with 64+ input channels: measured 53.4 vs 52.9 ms per step - still slower;
+        #   2          : everywhere the halo-resident kernels allow: 60.2 vs 53.6 ms per step (wgrad +17 %, conv1_2 5x slower).
+        self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "0"))
         assert self.conv_precision in (0, 2, 3, 6)
         self._amax_by_stream = {}
 

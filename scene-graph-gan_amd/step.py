@@ -97,16 +97,16 @@ class GanStep:
         self.side = torch.cuda.Stream(device=dev) if (overlap_streams and dev.type == "cuda") else None
 
     # ------------------------------------------------------------------------------------------------
-    def generator_forward(self, images, noise):
+    def generator_forward(self, images, noise, for_backward=True):
         """Generator.build_generator: fake logits [B,3,V] (a view of the critic's input slab)."""
         G = self.G
-        ctx = G.trunk.forward(images)
+        ctx = G.trunk.forward(images, for_backward) if for_backward is False else G.trunk.forward(images)
         G.head.precompute(ctx)
         st = G.head.state(1, self.B)
         G.head.forward(st, ctx, noise)
         return st, ctx
 
-    def _d_encoder_on_side_stream(self, images, zero_grads):
+    def _d_encoder_on_side_stream(self, images, zero_grads, for_backward=True):
         """D.finish_update (pending all-reduce + Adam), D's encoder forward and the step-invariant attention product,
         enqueued on the side stream; returns ctx. Call _join_side() before anything on the main stream reads them."""
         D = self.D
@@ -114,7 +114,7 @@ class GanStep:
             D.finish_update()
             if zero_grads:
                 D.zero_grads()
-            ctx = D.trunk.forward(images)
+            ctx = D.trunk.forward(images, for_backward) if for_backward is False else D.trunk.forward(images)
             D.head.precompute(ctx)
             return ctx
         main = torch.cuda.current_stream()
@@ -123,7 +123,7 @@ class GanStep:
             D.finish_update()
             if zero_grads:
                 D.zero_grads()
-            ctx = D.trunk.forward(images)
+            ctx = D.trunk.forward(images, for_backward) if for_backward is False else D.trunk.forward(images)
             D.head.precompute(ctx)
         return ctx
 
@@ -143,10 +143,10 @@ class GanStep:
         if D.pending is None or self.side is not None:
             ctx = self._d_encoder_on_side_stream(images, zero_grads=True)
             self.G.finish_update()
-            gst, _ = self.generator_forward(images, noise)
+            gst, _ = self.generator_forward(images, noise, for_backward=False)     # the critic update never differentiates G
         else:
             self.G.finish_update()
-            gst, _ = self.generator_forward(images, noise)
+            gst, _ = self.generator_forward(images, noise, for_backward=False)
             ctx = self._d_encoder_on_side_stream(images, zero_grads=True)
         self._join_side()
         fake_rows.copy_(gst.OUT[0])
@@ -185,13 +185,13 @@ class GanStep:
         G.finish_update()
         G.zero_grads()
         if D.pending is None or self.side is not None:
-            ctx = self._d_encoder_on_side_stream(images, zero_grads=False)   # independent of G's forward
+            ctx = self._d_encoder_on_side_stream(images, zero_grads=False, for_backward=False)   # independent of G's forward
             gst, gctx = self.generator_forward(images, noise)
         else:
             # the critic-gradient all-reduce launched at the end of critic_step runs under G's forward; only then does
             # D.finish_update() wait for it
             gst, gctx = self.generator_forward(images, noise)
-            ctx = self._d_encoder_on_side_stream(images, zero_grads=False)
+            ctx = self._d_encoder_on_side_stream(images, zero_grads=False, for_backward=False)   # only D's head is differentiated here
         fake = gst.OUT[0]
         self._join_side()
         st = D.head.state(1, B, "g")

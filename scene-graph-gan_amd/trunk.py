@@ -91,10 +91,13 @@ class Trunk:
         staging) instead of a separate pass: the activation a_j is never written.  Needs the statistics partials from this layer's
         conv epilogue and a consumer served by the halo-resident kernels in the conv precision in force."""
         K = self.K
+        mode = getattr(K, "ln_fusion", 0)        # 0 off, 1 forward-only passes with 64+ consumer channels, 2 everywhere possible
         for j, lay in enumerate(self.layers):
             lay["fuse_ln"] = False
-            if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and getattr(K, "ln_fusion", True)) or j + 1 >= len(self.layers):
+            if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and mode) or j + 1 >= len(self.layers):
                 continue
+            if mode == 1 and self.layers[j + 1]["cin"] < 64:
+                continue      # 32-channel consumers are staging-dominated: the prologue makes conv1_2 five times slower
             nxt = self.layers[j + 1]
             stats_ok = lay["tstats"] is not None and (lay["cin"] == 3 or (lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision
                                                                           and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])))
@@ -117,10 +120,14 @@ class Trunk:
                     lay["ws_mode"] = self.K.conv_precision
         self._plan_ln_fusion()
 
-    def forward(self, images):
-        """images [B,S,S,3] NHWC fp32, already standardised (train.py:172) -> downsampled as ctx [B, L, 512]."""
+    def forward(self, images, for_backward=True):
+        """images [B,S,S,3] NHWC fp32, already standardised (train.py:172) -> downsampled as ctx [B, L, 512].
+        for_backward=False (G in the critic update, D in the generator update: no encoder backward follows): LayerNorm + ELU of a
+        layer may be applied by the consuming convolution's patch staging instead of a pass of its own (K.ln_fusion = 1)."""
         assert tuple(images.shape) == (self.B, self.S, self.S, 3), images.shape
         K = self.K
+        fuse_ok = getattr(K, "ln_fusion", 0) == 2 or (getattr(K, "ln_fusion", 0) == 1 and not for_backward)
+        self._fwd_for_backward = for_backward
         self.images = images
         x = images
         ln_in = None            # (stats, gamma, beta) when x is a pre-LayerNorm tensor whose LN + ELU this layer applies itself
@@ -140,7 +147,7 @@ class Trunk:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             ln_in = None
             if lay["has_ln"]:
-                if lay.get("fuse_ln") and ts is not None:
+                if fuse_ok and lay.get("fuse_ln") and ts is not None:
                     # statistics only; the consumer normalises y while it stages its patches (forward and wgrad)
                     K.ln_finalize(ts, lay["gamma"], lay["beta"], lay["stats"], self._am(0, j), lay["out_shape"][1] * lay["out_shape"][2])
                     ln_in = (lay["stats"], lay["gamma"], lay["beta"])
@@ -160,6 +167,7 @@ class Trunk:
     def backward(self, dctx):
         """dctx [B, L, 512]: gradient w.r.t. `downsampled`. Writes every live conv / LN parameter gradient."""
         K, B = self.K, self.B
+        assert getattr(self, "_fwd_for_backward", True), "the last forward was run with for_backward=False"
         dy = dctx.view(B, self.Hf, self.Wf, FEAT_C)
         n = len(self.layers)
         f16 = self._f16()

@@ -37,9 +37,9 @@ def _recording_step(critic_iters, iterations=2):
     for net in (gs.G, gs.D):
         fwd = net.trunk.forward
 
-        def wrapped(images, _f=fwd, _k=net.kind):
+        def wrapped(images, *args, _f=fwd, _k=net.kind):
             log.append("encoder:" + _k)
-            return _f(images)
+            return _f(images, *args)
 
         net.trunk.forward = wrapped
     images, labels, _ = O.synth_batch(B, S, V, dtype=DT)
