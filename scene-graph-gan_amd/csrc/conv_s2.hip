@@ -35,6 +35,9 @@
 #define S2_PLB (S2_MAXSLOTS * 32)      // bytes of one plane of one patch buffer
 #define S2_NPASS 4                     // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256
 #define S2_BN 128
+#ifndef S2_SMALL_ITEMS
+#define S2_SMALL_ITEMS 256            // at most this many 224-position work items: use 128-position bands instead
+#endif
 #ifndef S2_SWZ
 #define S2_SWZ(slot) (((slot) >> 3) & 1)      // which 16-B half of a slot holds channels 0..7
 #endif
@@ -420,7 +423,7 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
   S2Params p = p_;
   const int ntn = p.N / S2_BN;
   // 224-position bands unless they give fewer work items than CUs (and no LayerNorm partials are asked for): then 128
-  const int mt = (!p.tile_stats && sgg_cdiv(p.M, S2_BAND) * ntn <= 256) ? 4 : 7;
+  const int mt = (!p.tile_stats && sgg_cdiv(p.M, S2_BAND) * ntn <= S2_SMALL_ITEMS) ? 4 : 7;
   p.nbands = sgg_cdiv(p.M, 32 * mt);
   int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile) pairs an XCD owns
   int gx = per_xcd < 64 ? per_xcd : 64;            // two resident workgroups on each of its 32 CUs

@@ -567,6 +567,9 @@ struct WgradPlan {
   size_t ws_bytes;
 };
 
+#ifndef SGG_WGRAD_WGS
+#define SGG_WGRAD_WGS 1536   // workgroups aimed at by the pixel split of the per-tap wgrad kernels
+#endif
 static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
   WgradPlan pl;
   const long long mpix = (long long)B * Ho * Wo;
@@ -582,7 +585,7 @@ static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, in
   pl.bnc = Cout >= 128 ? 128 : Cout;
   pl.tiles = (Cin / pl.bmc) * (Cout / pl.bnc);
   const int base = pl.tiles * KH * KW;
-  int ns = (1536 + base - 1) / base;
+  int ns = (SGG_WGRAD_WGS + base - 1) / base;
   const long long max_ns = mpix / 512 > 0 ? mpix / 512 : 1;
   if (ns > max_ns) ns = (int)max_ns;
   if (ns < 1) ns = 1;

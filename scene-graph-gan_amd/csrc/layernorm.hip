@@ -12,6 +12,9 @@
 #include "sgg_common.h"
 
 #define LN_EPS 1e-12f
+#ifndef SGG_LN_WGS
+#define SGG_LN_WGS 1536      // workgroups per launch of the streaming LayerNorm kernels (six per CU)
+#endif
 #define LN_CHUNK 4096  // elements per workgroup iteration: 256 threads x 4 x float4
 
 struct LnGeom {
@@ -26,7 +29,7 @@ static LnGeom ln_geom(int B, int HW, int C) {
   LnGeom g;
   g.B = B; g.C = C; g.HW = HW; g.N = (long long)HW * C;
   const int nchunks = (int)((g.N + LN_CHUNK - 1) / LN_CHUNK);
-  int G = (1536 + B - 1) / B;
+  int G = (SGG_LN_WGS + B - 1) / B;
   if (G > nchunks) G = nchunks;
   if (G < 1) G = 1;
   g.cpg = (nchunks + G - 1) / G;
