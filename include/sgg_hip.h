@@ -82,17 +82,23 @@ int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B
  * fwd writes a = ELU(LN(y)) and stats[b] = (mean, rstd).  bwd writes dy, dgamma, dbeta and (optional, may be
  * NULL) dbias_prev = sum_{b,h,w} dy = the BiasAddGrad of the convolution that produced y. */
 size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C);
-/* amax_out (optional): device word atomically max-ed with max|output| (the consumer convolution's f16 scaling) */
+/* amax_out (optional): device word atomically max-ed with max|output| (the consumer convolution's f16 scaling).
+ * Valid region (fwd and bwd): W == 0 -> the whole HW plane is normalised.  W > 0 -> the plane is an (HW / W) x W canvas that
+ * holds the layer's true (Hv x Wv) map at rows [y0, y0 + Hv), columns [x0, x0 + Wv) (odd image sizes such as the reference's
+ * 221 x 221, train.py:171, run on even canvases so that the tiled convolution kernels apply): statistics, gradients and
+ * parameter gradients cover the region only; a / dy are written as ZEROS outside it (the next convolution's zero padding).
+ * tile_stats must be NULL with W > 0. */
 int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
                               float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
-                              void* workspace, size_t workspace_bytes, void* stream);
+                              int W, int y0, int x0, int Hv, int Wv, void* workspace, size_t workspace_bytes, void* stream);
 /* statistics only: stats[b] = (mean, rstd) merged from the convolution's tile partials; amax_out max-ed with an upper bound of
  * max|ELU(LN(y))| (for the fp16 scaling of a consumer with an LN prologue) */
 int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_stats, const float* gamma, const float* beta, float* stats,
                                float* amax_out, int B, int HW, int C, void* stream);
 int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
                               const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
-                              float* amax_out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+                              float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---- initial LSTM state: tf.reduce_mean(downsampled, axis=(1,2)) -------------------------------------------
  * generator_with_attention.py:76-77.  Rows r in [0,R) use image r % B (R/B passes share one feature map). */

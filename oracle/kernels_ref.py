@@ -47,14 +47,22 @@ class RefKernels:
         (g,) = torch.autograd.grad(y, w0, dy)
         dw.copy_(g)
 
-    def ln_elu_fwd(self, y, gamma, beta, a, stats):
+    def ln_elu_fwd(self, y, gamma, beta, a, stats, region=None):
+        if region is not None:      # valid window of a canvas (sgg_hip.h): normalise the window, zeros elsewhere
+            r0, c0, hv, wv = region
+            a.zero_()
+            y, a = y[:, r0:r0 + hv, c0:c0 + wv], a[:, r0:r0 + hv, c0:c0 + wv]
         a.copy_(O.elu(O.layer_norm_tf(y, gamma, beta)))
         mean = y.mean(dim=(1, 2, 3))
         var = ((y - mean[:, None, None, None]) ** 2).mean(dim=(1, 2, 3))
         stats[:, 0] = mean
         stats[:, 1] = torch.rsqrt(var + O.LN_EPS)
 
-    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev):
+    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, region=None):
+        if region is not None:
+            r0, c0, hv, wv = region
+            dy.zero_()
+            y, da, dy = (t[:, r0:r0 + hv, c0:c0 + wv] for t in (y, da, dy))
         y0 = y.detach().clone().requires_grad_(True)
         g0 = gamma.detach().clone().requires_grad_(True)
         b0 = beta.detach().clone().requires_grad_(True)

@@ -25,6 +25,17 @@ struct LnGeom {
   int cpg;       // chunks per workgroup
 };
 
+// Valid region of an H x W canvas (odd image sizes run on an even canvas, trunk.py): statistics and gradients cover the
+// region only, outputs outside it are written as zeros (= the zero padding the next convolution expects).
+struct LnMask {
+  int W, y0, x0, Hv, Wv, logC;
+};
+__device__ __forceinline__ bool ln_valid(const LnMask& m, long long e) {
+  const int pix = (int)(e >> m.logC);
+  const int py = pix / m.W, px = pix - py * m.W;
+  return (unsigned)(py - m.y0) < (unsigned)m.Hv && (unsigned)(px - m.x0) < (unsigned)m.Wv;
+}
+
 static LnGeom ln_geom(int B, int HW, int C) {
   LnGeom g;
   g.B = B; g.C = C; g.HW = HW; g.N = (long long)HW * C;
@@ -38,8 +49,9 @@ static LnGeom ln_geom(int B, int HW, int C) {
 }
 
 // ---- forward -----------------------------------------------------------------------------------------
+template <bool MASK>
 __global__ __launch_bounds__(256) void ln_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
-                                                               long long N, int G, int cpg) {
+                                                               long long N, int G, int cpg, LnMask mk) {
   __shared__ float red[4];
   const int b = blockIdx.y, g = blockIdx.x;
   const float* yb = y + (size_t)b * N;
@@ -48,24 +60,30 @@ __global__ __launch_bounds__(256) void ln_stats_partial_kernel(const float* __re
     const long long base = ((long long)g * cpg + c) * LN_CHUNK;
     if (base >= N) break;
     f32x4 v[4];
-    float s = 0.f;
+    float s = 0.f, cnt = 0.f;
+    int okm = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = base + (threadIdx.x + 256 * j) * 4;
-      if (e < N) {
+      if (e < N && (!MASK || ln_valid(mk, e))) {
         v[j] = *reinterpret_cast<const f32x4*>(yb + e);
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        cnt += 4.f;
+        okm |= 1 << j;
       } else {
         v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    const float n_c = (float)((N - base) < LN_CHUNK ? (N - base) : LN_CHUNK);
+    float n_c = (float)((N - base) < LN_CHUNK ? (N - base) : LN_CHUNK);
+    if constexpr (MASK) {
+      n_c = block_sum_256(cnt, red);
+      if (n_c == 0.f) continue;          // (uniform: the whole chunk lies outside the valid region)
+    }
     const float mean_c = block_sum_256(s, red) / n_c;
     float q = 0.f, dm = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const long long e = base + (threadIdx.x + 256 * j) * 4;
-      if (e < N) {
+      if ((okm >> j) & 1) {
         const f32x4 d = v[j] - mean_c;
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         dm = fmaxf(fmaxf(dm, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
@@ -110,15 +128,17 @@ __device__ __forceinline__ void ln_merge(const float* __restrict__ part, int G, 
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 
+template <bool MASK>
 __global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ part,
                                                            float* __restrict__ a, float* __restrict__ stats, long long N,
-                                                           int C, int G, int cpg, float* __restrict__ amax_out) {
+                                                           int C, int G, int cpg, float* __restrict__ amax_out, LnMask mk,
+                                                           float nvalid) {
   __shared__ float red[4];
   const int b = blockIdx.y, g = blockIdx.x;
   float mean, rstd;
   float amax = 0.f;
-  ln_merge(part + (size_t)b * G * SGG_TS, G, (float)N, red, mean, rstd);
+  ln_merge(part + (size_t)b * G * SGG_TS, G, MASK ? nvalid : (float)N, red, mean, rstd);
   if (g == 0 && threadIdx.x == 0) {
     stats[b * 2 + 0] = mean;
     stats[b * 2 + 1] = rstd;
@@ -137,6 +157,10 @@ __global__ __launch_bounds__(256) void ln_apply_elu_kernel(const float* __restri
     for (int j = 0; j < 4; ++j) {
       const long long e = base + (threadIdx.x + 256 * j) * 4;
       if (e < N) {
+        if (MASK && !ln_valid(mk, e)) {
+          *reinterpret_cast<f32x4*>(ab + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
         const f32x4 v = *reinterpret_cast<const f32x4*>(yb + e);
         f32x4 o = v * inv + shift;
         o[0] = elu1(o[0]); o[1] = elu1(o[1]); o[2] = elu1(o[2]); o[3] = elu1(o[3]);
@@ -184,10 +208,12 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
 
 // ---- backward ----------------------------------------------------------------------------------------
 // per workgroup: sspart[b][g] = (sum dxhat, sum dxhat*xhat); chpart[b][g][3][C] = (sum dn, sum dn*xhat, sum xhat)
+template <bool MASK>
 __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __restrict__ y, const float* __restrict__ da,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ stats, float* __restrict__ sspart,
-                                                             float* __restrict__ chpart, long long N, int C, int G, int cpg) {
+                                                             float* __restrict__ chpart, long long N, int C, int G, int cpg,
+                                                             LnMask mk) {
   __shared__ float red[4];
   __shared__ float chs[256 * 12];
   const int b = blockIdx.y, g = blockIdx.x;
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = base + (threadIdx.x + 256 * j) * 4;
-      if (e < N) {
+      if (e < N && (!MASK || ln_valid(mk, e))) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(yb + e);
         const f32x4 d = *reinterpret_cast<const f32x4*>(db + e);
         const f32x4 xh = (v - mean) * rstd;
@@ -300,11 +326,12 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
   }
 }
 
+template <bool MASK>
 __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ da,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ stats, const float* __restrict__ sspart,
                                                            float* __restrict__ dy, long long N, int C, int G, int cpg,
-                                                           float* __restrict__ amax_out) {
+                                                           float* __restrict__ amax_out, LnMask mk, float nvalid) {
   __shared__ float red[4];
   const int b = blockIdx.y, g = blockIdx.x;
   const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
@@ -314,8 +341,8 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
     a1 += sspart[((size_t)b * G + i) * 2 + 0];
     a2 += sspart[((size_t)b * G + i) * 2 + 1];
   }
-  const float m1 = block_sum_256(a1, red) / (float)N;
-  const float m2 = block_sum_256(a2, red) / (float)N;
+  const float m1 = block_sum_256(a1, red) / (MASK ? nvalid : (float)N);
+  const float m2 = block_sum_256(a2, red) / (MASK ? nvalid : (float)N);
   const float* yb = y + (size_t)b * N;
   const float* db = da + (size_t)b * N;
   float* ob = dy + (size_t)b * N;
@@ -329,6 +356,10 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
     for (int j = 0; j < 4; ++j) {
       const long long e = base + (threadIdx.x + 256 * j) * 4;
       if (e < N) {
+        if (MASK && !ln_valid(mk, e)) {
+          *reinterpret_cast<f32x4*>(ob + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
         const f32x4 v = *reinterpret_cast<const f32x4*>(yb + e);
         const f32x4 d = *reinterpret_cast<const f32x4*>(db + e);
         const f32x4 xh = (v - mean) * rstd;
@@ -364,26 +395,50 @@ static int ln_check(const char* name, int B, int HW, int C, size_t ws_bytes, voi
   return SGG_OK;
 }
 
+// Valid-region argument of the two entry points below: W == 0 -> every pixel of the HW plane is valid; otherwise the plane is
+// an (HW / W) x W canvas whose valid region is rows [y0, y0 + Hv) x columns [x0, x0 + Wv).
+static int ln_mask(const char* name, int HW, int C, int W, int y0, int x0, int Hv, int Wv, LnMask& mk, float& nvalid) {
+  mk = LnMask{W, y0, x0, Hv, Wv, 0};
+  nvalid = (float)((long long)HW * C);
+  if (W == 0) return SGG_OK;
+  SGG_CHECK_ARG(W > 0 && HW % W == 0 && y0 >= 0 && x0 >= 0 && Hv > 0 && Wv > 0 && y0 + Hv <= HW / W && x0 + Wv <= W,
+                "%s: valid region (%d,%d)+(%dx%d) outside the %dx%d canvas", name, y0, x0, Hv, Wv, HW / W, W);
+  while ((1 << mk.logC) < C) ++mk.logC;
+  nvalid = (float)((long long)Hv * Wv * C);
+  return SGG_OK;
+}
+
 // tile_stats / n_tile_stats (optional): [B][n_tile_stats][4] (count, mean, M2, max |y - mean|) partials of y already produced by the
-// convolution's epilogue (sgg_conv2d_nhwc_fwd); the statistics pass over y is then skipped.
+// convolution's epilogue (sgg_conv2d_nhwc_fwd); the statistics pass over y is then skipped.  (Not with a valid region: the
+// convolution's partials cover the whole canvas.)
 extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
                                          float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
-                                         void* ws, size_t ws_bytes, void* stream) {
+                                         int W, int y0, int x0, int Hv, int Wv, void* ws, size_t ws_bytes, void* stream) {
   SGG_CHECK_ARG(y && gamma && beta && a && stats, "sgg_layernorm_hwc_elu_fwd: null pointer");
   int rc = ln_check("sgg_layernorm_hwc_elu_fwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
+  LnMask mk;
+  float nvalid;
+  if ((rc = ln_mask("sgg_layernorm_hwc_elu_fwd", HW, C, W, y0, x0, Hv, Wv, mk, nvalid))) return rc;
   const LnGeom g = ln_geom(B, HW, C);
   hipStream_t st = (hipStream_t)stream;
   if (tile_stats && n_tile_stats > 0) {
-    hipLaunchKernelGGL(ln_apply_elu_kernel, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, tile_stats, a, stats, g.N, C,
-                       n_tile_stats, g.cpg, amax_out);
+    SGG_CHECK_ARG(W == 0, "sgg_layernorm_hwc_elu_fwd: tile_stats cannot be combined with a valid region");
+    hipLaunchKernelGGL(ln_apply_elu_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, tile_stats, a, stats, g.N, C,
+                       n_tile_stats, g.cpg, amax_out, mk, nvalid);
     SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_fwd");
     return SGG_OK;
   }
   float* part = (float*)ws;
-  hipLaunchKernelGGL(ln_stats_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg);
-  hipLaunchKernelGGL(ln_apply_elu_kernel, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)part, a, stats, g.N,
-                     C, g.G, g.cpg, amax_out);
+  if (W == 0) {
+    hipLaunchKernelGGL(ln_stats_partial_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg, mk);
+    hipLaunchKernelGGL(ln_apply_elu_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)part, a, stats,
+                       g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
+  } else {
+    hipLaunchKernelGGL(ln_stats_partial_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg, mk);
+    hipLaunchKernelGGL(ln_apply_elu_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)part, a, stats,
+                       g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
+  }
   SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_fwd");
   return SGG_OK;
 }
@@ -401,21 +456,34 @@ extern "C" int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_st
 
 extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
                                          const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
-                                         float* amax_out, int B, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+                                         float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* ws,
+                                         size_t ws_bytes, void* stream) {
   SGG_CHECK_ARG(y && da && gamma && beta && stats && dy && dgamma && dbeta, "sgg_layernorm_hwc_elu_bwd: null pointer");
   int rc = ln_check("sgg_layernorm_hwc_elu_bwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
+  LnMask mk;
+  float nvalid;
+  if ((rc = ln_mask("sgg_layernorm_hwc_elu_bwd", HW, C, W, y0, x0, Hv, Wv, mk, nvalid))) return rc;
   const LnGeom g = ln_geom(B, HW, C);
   hipStream_t st = (hipStream_t)stream;
   float* sspart = (float*)ws + (size_t)B * g.G * SGG_TS;
   float* chpart = sspart + (size_t)B * g.G * 2;
-  hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart, g.N, C,
-                     g.G, g.cpg);
   const size_t sm = (size_t)(2 * B + LNF_BL * 32 * 3) * sizeof(float);
+  const int hw_valid = W == 0 ? HW : Hv * Wv;
+  if (W == 0)
+    hipLaunchKernelGGL(ln_bwd_partial_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart,
+                       g.N, C, g.G, g.cpg, mk);
+  else
+    hipLaunchKernelGGL(ln_bwd_partial_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart,
+                       g.N, C, g.G, g.cpg, mk);
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sspart,
-                     (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, HW);
-  hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, (const float*)sspart, dy,
-                     g.N, C, g.G, g.cpg, amax_out);
+                     (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, hw_valid);
+  if (W == 0)
+    hipLaunchKernelGGL(ln_bwd_apply_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats,
+                       (const float*)sspart, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
+  else
+    hipLaunchKernelGGL(ln_bwd_apply_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats,
+                       (const float*)sspart, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
   SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd");
   return SGG_OK;
 }

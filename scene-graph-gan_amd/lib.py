@@ -38,8 +38,8 @@ SIGNATURES = {
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
     "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 4 + [_vp, _sz, _vp]),
-    "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 9 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -312,18 +312,29 @@ class HipKernels:
             _p(ws), ws.numel(), self._stream())),
             "sgg_conv2d_nhwc_wgrad")
 
-    def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None, tile_stats=None):
-        """tile_stats [B, n, 3]: per-tile (count, mean, M2) written by conv_fwd's epilogue (skips the statistics pass)."""
+    @staticmethod
+    def _region(region, H, W):
+        """(y0, x0, Hv, Wv) valid region of the H x W plane -> the C ABI's (W, y0, x0, Hv, Wv); W = 0: everything is valid."""
+        if region is None:
+            return (0, 0, 0, 0, 0)
+        y0, x0, hv, wv = region
+        assert 0 <= y0 and 0 <= x0 and y0 + hv <= H and x0 + wv <= W, (region, H, W)
+        return (W, y0, x0, hv, wv)
+
+    def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None, tile_stats=None, region=None):
+        """tile_stats [B, n, 4]: per-tile (count, mean, M2, max dev) written by conv_fwd's epilogue (skips the statistics pass).
+        region (y0, x0, Hv, Wv): LayerNorm over that window of every sample only; `a` is written as zeros outside it."""
         self._dev(y, gamma, beta, a, stats, amax_out, tile_stats)
         B, H, W, C = y.shape
+        assert region is None or tile_stats is None
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
         ws = self.workspace(need)
         nts = 0 if tile_stats is None else tile_stats.shape[1]
         # algorithmic bytes: read y (twice without epilogue statistics: statistics pass + apply pass), write a
         nb = 4.0 * y.numel() * (2 if nts else 3)
         self._check(self._timed("ln_elu_fwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_fwd(
-            _p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), _p(tile_stats), nts, B, H * W, C, _p(ws), ws.numel(),
-            self._stream()), nb), "sgg_layernorm_hwc_elu_fwd")
+            _p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), _p(tile_stats), nts, B, H * W, C,
+            *self._region(region, H, W), _p(ws), ws.numel(), self._stream()), nb), "sgg_layernorm_hwc_elu_fwd")
 
     def ln_finalize(self, tile_stats, gamma, beta, stats, amax_out, hw):
         """Statistics only: stats [B,2] = (mean, rstd) from the conv epilogue's tile partials [B,n,4]; amax_out (1 word, may be None)
@@ -339,7 +350,7 @@ class HipKernels:
         return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
                 self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) == 1)
 
-    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None):
+    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None):
         self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out)
         B, H, W, C = y.shape
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
@@ -347,7 +358,7 @@ class HipKernels:
         # algorithmic bytes: the reduction pass reads y and da, the apply pass reads them again and writes dy
         self._check(self._timed("ln_elu_bwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_bwd(
             _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma), _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C,
-            _p(ws), ws.numel(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")
+            *self._region(region, H, W), _p(ws), ws.numel(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")
 
     # -- heads -----------------------------------------------------------------------------------------
     def spatial_mean_fwd(self, ctx, out_c, out_h):

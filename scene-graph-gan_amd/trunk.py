@@ -8,6 +8,12 @@ LayerNorms (:59-62) never reach `downsampled` and are neither computed nor given
 HBM layout: per layer the conv output y_i and the activation a_i = ELU(LN(y_i)) stay resident for the backward
 pass (5.6 GB per network at batch 64 / 224x224 - sized for 288 GB of HBM3E, nothing is recomputed); the
 backward pass ping-pongs two scratch tensors (dA, dY) of the largest activation size.
+
+Odd image sizes (the reference trains on 221 x 221, train.py:171: maps of 221, 111, 56, 28, 14) run on EVEN CANVASES
+(224, 112, 56, 28, 14) so that the tiled halo / band / halo-wgrad kernels apply: the true map of a stage sits at an offset inside
+its canvas (3 for 221, 1 for 111, 0 from 56 on), chosen such that the canvas convolution's own SAME padding lines up with the true
+one; the LayerNorm kernels normalise the valid window only and write zeros outside it, which is exactly the zero padding the
+next convolution (and, in the backward pass, the next dgrad / wgrad) must see.  See `plan_canvas`.
 """
 from __future__ import annotations
 
@@ -16,20 +22,60 @@ import torch
 from .params import CONV_SPECS, FEAT_C, conv_name, ln_name, same_pads
 
 
+def plan_canvas(S):
+    """Per live conv layer: (canvas_in, offset_in, true_in, canvas_out, offset_out, true_out), or None when the plain grid is used.
+
+    A canvas convolution (SAME padding computed from the canvas size, pad_c in front) reproduces the true convolution (pad_t in
+    front) at out[q] = true_out[q - o_out] iff  o_in = stride * o_out + pad_t - pad_c  and the input is zero outside its valid
+    window.  Working back from the last layer (offset 0, canvas = true size) this fixes every offset; the plan is rejected when an
+    offset would be negative, a window would not fit its canvas or the canvas is over 1.3x the image (then the plain, possibly odd,
+    grid is used)."""
+    specs = [(k, s) for (_, _, _, k, s, _, live) in CONV_SPECS if live]
+    true = [S]
+    for k, s in specs:
+        true.append(same_pads(true[-1], k, s)[0])
+    canvas, off = [0] * len(true), [0] * len(true)
+    canvas[-1] = true[-1]
+    for j in range(len(specs) - 1, -1, -1):
+        k, s = specs[j]
+        canvas[j] = canvas[j + 1] * s
+        pad_t, pad_c = same_pads(true[j], k, s)[1], same_pads(canvas[j], k, s)[1]
+        off[j] = s * off[j + 1] + pad_t - pad_c
+        if off[j] < 0 or off[j] + true[j] > canvas[j] or same_pads(canvas[j], k, s)[0] != canvas[j + 1]:
+            return None
+    if canvas == true or canvas[0] ** 2 > 1.3 * true[0] ** 2:      # (nothing to do / the canvas would cost more than it saves)
+        return None
+    return [(canvas[j], off[j], true[j], canvas[j + 1], off[j + 1], true[j + 1]) for j in range(len(specs))]
+
+
 class Trunk:
     def __init__(self, K, arena, grad_views, B, S):
         self.K, self.B, self.S = K, B, S
         dev, dt = arena.flat.device, arena.flat.dtype
         p, g = arena.views, grad_views
         self.layers = []
-        h = w = S
-        cin_shape = (B, S, S, 3)
+        plan = plan_canvas(S) if getattr(K, "canvas", True) else None
+        S_in = plan[0][0] if plan else S
+        # the image inside its zero canvas (odd sizes): filled by forward(), zero elsewhere for good
+        self.img_canvas = torch.zeros((B, S_in, S_in, 3), device=dev, dtype=dt) if plan else None
+        self.img_off = plan[0][1] if plan else 0
+        h = w = S_in
+        cin_shape = (B, S_in, S_in, 3)
         max_act = 0
+        li = -1
         for (i, cin, cout, k, s, has_ln, live) in CONV_SPECS:
             if not live:
                 continue
+            li += 1
             ho, wo = same_pads(h, k, s)[0], same_pads(w, k, s)[0]
+            region = None
+            if plan:
+                c_out, o_out, t_out = plan[li][3:]
+                assert c_out == ho
+                if (c_out, o_out) != (t_out, 0):
+                    region = (o_out, o_out, t_out, t_out)      # valid window of this layer's output canvas
             lay = {
+                "region": region,
                 "i": i, "cin": cin, "cout": cout, "k": k, "s": s, "has_ln": has_ln,
                 "in_shape": cin_shape, "out_shape": (B, ho, wo, cout),
                 "w": p[conv_name(i) + "/kernel"], "b": p[conv_name(i) + "/bias"],
@@ -49,7 +95,7 @@ class Trunk:
                 lay["ws_fwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
                 lay["ws_bwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
             lay["tstats"] = None
-            if has_ln and hasattr(K, "conv_tile_stats_count"):
+            if has_ln and hasattr(K, "conv_tile_stats_count") and region is None:
                 nts = K.conv_tile_stats_count((B, ho, wo, cout), cin, k, s, lay["ws_layout"])
                 if nts > 0:     # the conv epilogue emits the LayerNorm partial statistics for this shape
                     lay["tstats"] = torch.zeros((B, nts, 4), device=dev, dtype=dt)
@@ -94,7 +140,7 @@ class Trunk:
         mode = getattr(K, "ln_fusion", 0)        # 0 off, 1 forward-only passes with 64+ consumer channels, 2 everywhere possible
         for j, lay in enumerate(self.layers):
             lay["fuse_ln"] = False
-            if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and mode) or j + 1 >= len(self.layers):
+            if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and mode) or j + 1 >= len(self.layers) or lay["region"]:
                 continue
             if mode == 1 and self.layers[j + 1]["cin"] < 64:
                 continue      # 32-channel consumers are staging-dominated: the prologue makes conv1_2 five times slower
@@ -128,6 +174,10 @@ class Trunk:
         K = self.K
         fuse_ok = getattr(K, "ln_fusion", 0) == 2 or (getattr(K, "ln_fusion", 0) == 1 and not for_backward)
         self._fwd_for_backward = for_backward
+        if self.img_canvas is not None:
+            o = self.img_off
+            self.img_canvas[:, o:o + self.S, o:o + self.S].copy_(images)
+            images = self.img_canvas
         self.images = images
         x = images
         ln_in = None            # (stats, gamma, beta) when x is a pre-LayerNorm tensor whose LN + ELU this layer applies itself
@@ -155,7 +205,10 @@ class Trunk:
                     lay["fused_now"] = True
                     continue
                 lay["fused_now"] = False
-                if self._f16() or ts is not None:
+                if lay["region"] is not None:
+                    K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], *([self._am(0, j), None] if self._f16() else []),
+                                 region=lay["region"])
+                elif self._f16() or ts is not None:
                     K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], self._am(0, j), ts)
                 else:
                     K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"])
@@ -200,7 +253,10 @@ class Trunk:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"] if ws is not None else 0)
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])
-            if f16:
+            if prev["region"] is not None:
+                K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"],
+                             *([self._am(1, j - 1)] if f16 else []), region=prev["region"])
+            elif f16:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"],
                              self._am(1, j - 1))
             else:

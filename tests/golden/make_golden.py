@@ -57,7 +57,9 @@ if __name__ == "__main__":
             # two samples at configs[4] layer shapes (448x448: L = 784, attention W [401920+512, 784])
             ("configs4_shape_b2_golden.npz", dict(B=2, S=448, V=50, small=True)),
             # configs[3] vocabulary (70 000: decoder [512,70000], embedding [70000,300]) on small images
-            ("configs3_vocab_b2_golden.npz", dict(B=2, S=64, V=70000, small=True))]
+            ("configs3_vocab_b2_golden.npz", dict(B=2, S=64, V=70000, small=True)),
+            # the reference's real-data resolution (train.py:171 resizes to 221x221: odd maps 221, 111, then 56, 28, 14)
+            ("realdata_221px_b2_golden.npz", dict(B=2, S=221, V=1000, small=True))]
     only = sys.argv[1:]
     for name, kw in todo:
         if only and name not in only:

@@ -158,10 +158,10 @@ def tensor_err(a, b):
 
 
 E2E = [("configs1_shape_b2_golden.npz", 2, 224, 1000), ("configs4_shape_b2_golden.npz", 2, 448, 50),
-       ("configs3_vocab_b2_golden.npz", 2, 64, 70000)]
+       ("configs3_vocab_b2_golden.npz", 2, 64, 70000), ("realdata_221px_b2_golden.npz", 2, 221, 1000)]
 
 
-@pytest.mark.parametrize("gold,B,S,V", E2E, ids=["configs1_224px_V1000", "configs4_448px_L784", "configs3_V70000"])
+@pytest.mark.parametrize("gold,B,S,V", E2E, ids=["configs1_224px_V1000", "configs4_448px_L784", "configs3_V70000", "realdata_221px_canvas"])
 def test_step_matches_oracle_and_golden(hip, gold, B, S, V):
     """G forward + one critic update + one generator update on B = 2 rows at the layer / vocabulary sizes of configs[1], [4], [3]
     (default conv precision of the product path) vs the CPU oracle run here on the same seeded inputs, and vs the committed
@@ -171,6 +171,9 @@ def test_step_matches_oracle_and_golden(hip, gold, B, S, V):
     images, labels, onehot = O.synth_batch(B, S, V)
     noise0, noise1, alpha = O.synth_noise(B, 0), O.synth_noise(B, 1), O.synth_alpha(B, 0)
     gs = GanStep(hip, V, S, B, lam=10.0, g_state=gp, d_state=dp)
+    if S == 221:     # odd maps run on even canvases (trunk.plan_canvas) through the same halo / band kernels as 224x224
+        assert gs.G.trunk.img_canvas is not None and gs.G.trunk.layers[0]["in_shape"][1] == 224
+        assert gs.G.trunk.layers[1]["ws_layout"] == 1 and gs.G.trunk.layers[7]["ws_layout"] == 2
     G = np.load(os.path.join(GOLD_DIR, gold))
     st, _ = gs.generator_forward(images.cuda(), noise0.cuda())
     logits = st.OUT[0].cpu()

@@ -154,6 +154,44 @@ def test_layernorm_elu(hip, ref, shape):
     close(dbias, dbias_ref, rtol=5e-5, atol=2e-5, what="ln dbias_prev")
 
 
+@pytest.mark.parametrize("shape,region", [((2, 16, 16, 32), (1, 1, 15, 15)), ((2, 112, 112, 32), (1, 1, 111, 111)),
+                                          ((1, 224, 224, 32), (3, 3, 221, 221)), ((3, 12, 12, 128), (2, 3, 9, 7)),
+                                          ((2, 8, 8, 512), (0, 0, 8, 7))])
+def test_layernorm_elu_valid_region(hip, ref, shape, region):
+    """Canvas mode (odd image sizes, trunk.plan_canvas): statistics / gradients over the window only, zeros written outside;
+    canvas pixels outside the window hold garbage (1e6 here) that must not leak into anything."""
+    B, H, W, C = shape
+    r0, c0, hv, wv = region
+    inside = torch.zeros((1, H, W, 1), dtype=torch.bool)
+    inside[:, r0:r0 + hv, c0:c0 + wv] = True
+    y = torch.where(inside, rnd(shape, 7, 2.0) + 0.3, torch.full(shape, 1e6))
+    da = torch.where(inside, rnd(shape, 10), torch.full(shape, -1e6))
+    gamma, beta = 1.0 + rnd((C,), 8, 0.2), rnd((C,), 9, 0.2)
+    a_ref = torch.empty(shape, dtype=torch.float64)
+    st_ref = torch.empty((B, 2), dtype=torch.float64)
+    ref.ln_elu_fwd(y.double(), gamma.double(), beta.double(), a_ref, st_ref, region=region)
+    dy_ref = torch.empty(shape, dtype=torch.float64)
+    dg_ref, db_ref, dbias_ref = (torch.empty(C, dtype=torch.float64) for _ in range(3))
+    ref.ln_elu_bwd(y.double(), da.double(), gamma.double(), beta.double(), st_ref, dy_ref, dg_ref, db_ref, dbias_ref, region=region)
+    yd, gd, bd, dad = dev(y), dev(gamma), dev(beta), dev(da)
+    a = torch.full(shape, float("nan"), device="cuda")
+    st = torch.empty((B, 2), device="cuda")
+    amax = torch.zeros(2, device="cuda")
+    hip.ln_elu_fwd(yd, gd, bd, a, st, amax[0:1], region=region)
+    close(a, a_ref, what="ln fwd (region)")
+    close(st, st_ref, what="ln stats (region)")
+    assert torch.equal(a.cpu() == 0, (a_ref == 0)), "zeros exactly outside the window"
+    assert abs(float(amax[0]) - float(a_ref.abs().max())) <= 1e-5 * float(a_ref.abs().max())
+    dy = torch.full(shape, float("nan"), device="cuda")
+    dg, db, dbias = (torch.full((C,), float("nan"), device="cuda") for _ in range(3))
+    hip.ln_elu_bwd(yd, dad, gd, bd, st, dy, dg, db, dbias, amax[1:2], region=region)
+    close(dy, dy_ref, rtol=5e-5, what="ln bwd dy (region)")
+    close(dg, dg_ref, rtol=5e-5, what="ln dgamma (region)")
+    close(db, db_ref, rtol=5e-5, what="ln dbeta (region)")
+    close(dbias, dbias_ref, rtol=5e-5, atol=2e-5, what="ln dbias_prev (region)")
+    assert abs(float(amax[1]) - float(dy_ref.abs().max())) <= 1e-4 * float(dy_ref.abs().max())
+
+
 GEMM_CASES = [(8, 16, 8704), (64, 196, 4096), (24, 50, 512), (24, 2048, 562), (64, 300, 1000), (8, 1, 512),
               (70, 130, 33), (192, 2048, 1324)]
 

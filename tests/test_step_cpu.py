@@ -29,9 +29,9 @@ def rel_err(a, b, floor=1e-6):
     return float((a - b).abs().max() / (b.abs().max() + floor))
 
 
-@pytest.fixture(scope="module")
-def setup():
-    B, S, V = 2, 32, 11
+@pytest.fixture(scope="module", params=[32, 29])     # 29: odd maps (29, 15) on even canvases (trunk.plan_canvas), then 8, 4, 2
+def setup(request):
+    B, S, V = 2, request.param, 11
     gp, dp = make_states(V, S)
     images, labels, onehot = O.synth_batch(B, S, V, dtype=DT)
     K = RefKernels()
