@@ -10,16 +10,25 @@ import sgg_amd  # noqa: E402,F401
 from sgg_amd.lib import HipKernels  # noqa: E402
 
 
-def timeit(fn, n=20):
+_FLUSH = None
+
+
+def timeit(fn, n=10):
+    """Mean microseconds of fn(); 1 GB of unrelated traffic before every call, so nothing of the previous call is still cached."""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(256 << 20, device="cuda")
     fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    tot = 0.0
     for _ in range(n):
+        _FLUSH.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / n * 1e3
 
 
 def main():
