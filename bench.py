@@ -210,7 +210,10 @@ def main():
     ap.add_argument("--ci10-steps", type=int, default=2, help="iterations of the critic_iters = 10 secondary leg (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="add per-layer conv timings to the JSON line")
-    ap.add_argument("--overlap-streams", action="store_true", help="run the two encoders' forwards on two HIP streams (+3 %%)")
+    ap.add_argument("--two-stream-steps", type=int, default=5, help="steps of the secondary two-stream leg (0 = skip)")
+    ap.add_argument("--overlap-streams", action="store_true",
+                    help="time the two-stream schedule itself (D's encoder beside G's forward, filter gradients beside dgrad + LayerNorm "
+                         "backward: +4 %%; per-kernel event durations are then no roofline evidence)")
     ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 2, 3, 6],
                     help="conv contraction: 2 = scaled fp16 pieces, 3 products (default), 6 = bf16 pieces, 6 products, "
                          "0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance)")
@@ -238,7 +241,7 @@ def main():
     reducer = dpmod.GradReducer() if world > 1 else None
     gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer,
                  overlap_streams=args.overlap_streams)
-    extra = 2 + (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0)
+    extra = 2 + (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0) + (args.two_stream_steps + 1)
     total_steps = args.warmup + args.steps
     images, labels, noises, alphas = synth_inputs(B * world, S, V, (total_steps + extra) * (CI + 1), rank, world, dev)
 
@@ -328,6 +331,24 @@ def main():
             out["rccl"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "bucket_bytes": reducer.bucket_elems * 4,
                            "allreduce_bytes_per_step": 4 * (gs.G.arena.live_numel + CI * gs.D.arena.live_numel),
                            "ms_per_step_without_allreduce": ms_off, "allreduce_ms_exposed": ms_on - ms_off}
+
+    # ---- the same workload on the two-stream schedule (GanStep(overlap_streams=True): D's encoder beside G's forward, filter
+    # gradients beside the dgrad -> LayerNorm-backward chain; bit-identical results, tests/test_concurrency_gpu.py).  Not the
+    # headline: concurrent kernels make the per-kernel event durations of `roofline` meaningless, so the timed region is serial.
+    if not args.overlap_streams and args.two_stream_steps > 0:
+        gs.side = torch.cuda.Stream(device=dev)
+        gs.G.trunk.enable_wgrad_overlap(gs.side)
+        gs.D.trunk.enable_wgrad_overlap(gs.side)
+        one_step(next_k)
+        dt2, _ = timed(next_k + 1, args.two_stream_steps, False)
+        next_k += args.two_stream_steps + 1
+        gs.side = None
+        gs.G.trunk.enable_wgrad_overlap(None)
+        gs.D.trunk.enable_wgrad_overlap(None)
+        if rank == 0:
+            out["two_stream"] = {"value": B * world * args.two_stream_steps / dt2, "unit": "triples/sec", "steps": args.two_stream_steps,
+                                 "ms_per_step": 1e3 * dt2 / args.two_stream_steps,
+                                 "schedule": "--overlap-streams: same kernels, same results, independent launches on a second HIP stream"}
 
     # ---- the same workload in native f32 MFMA arithmetic, same run (the reference arithmetic is IEEE fp32) -----------------
     if K.conv_precision != 0 and args.f32_steps > 0:

@@ -95,6 +95,10 @@ class GanStep:
         # the MFMA-bound convolutions of the other, launch tails are filled).  Measured +3 % triples/s; off by
         # default because concurrent kernels make per-kernel durations (the roofline measurement) meaningless.
         self.side = torch.cuda.Stream(device=dev) if (overlap_streams and dev.type == "cuda") else None
+        if self.side is not None:
+            # backward: filter gradients beside the dgrad -> LayerNorm-backward chain (trunk.enable_wgrad_overlap)
+            self.G.trunk.enable_wgrad_overlap(self.side)
+            self.D.trunk.enable_wgrad_overlap(self.side)
 
     # ------------------------------------------------------------------------------------------------
     def generator_forward(self, images, noise, for_backward=True):

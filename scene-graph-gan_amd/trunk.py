@@ -217,6 +217,14 @@ class Trunk:
                 x = lay["y"]
         return x.view(self.B, self.L, FEAT_C)
 
+    def enable_wgrad_overlap(self, stream):
+        """Run the filter gradients on `stream` beside the dgrad -> LayerNorm-backward chain of the main stream (they only share
+        their input dy_j): the MFMA-bound wgrad kernels fill the matrix cores while the HBM-bound LayerNorm passes run.  Costs a
+        second dY scratch tensor (wgrad_j still reads dy_j while LayerNorm backward j-1 writes dy_{j-1})."""
+        self.wgrad_stream = stream
+        if stream is not None and getattr(self, "_dY2", None) is None:
+            self._dY2 = torch.empty_like(self._dY)
+
     def backward(self, dctx):
         """dctx [B, L, 512]: gradient w.r.t. `downsampled`. Writes every live conv / LN parameter gradient."""
         K, B = self.K, self.B
@@ -224,21 +232,39 @@ class Trunk:
         dy = dctx.view(B, self.Hf, self.Wf, FEAT_C)
         n = len(self.layers)
         f16 = self._f16()
+        side = getattr(self, "wgrad_stream", None)
+        if side is not None and any(l.get("fused_now") for l in self.layers):
+            side = None
+        main = torch.cuda.current_stream() if side is not None else None
+        dybufs = [self._dY, self._dY2] if side is not None else [self._dY]
+        reader_done = [None] * len(dybufs)        # event: the wgrad that reads this dY buffer has finished
         if f16:
             K.fill(self.amax[1], 0.0)
             K.absmax(dy, self._am(1, n - 1))
+        cur = -1                                   # dY buffer holding dy (-1: the caller's dctx)
         for j in range(n - 1, -1, -1):
             lay = self.layers[j]
             prv = self.layers[j - 1] if j else None
-            if prv is not None and prv.get("fused_now"):
-                # the input activation was never written: the wgrad kernel applies LayerNorm + ELU to the producing layer's y
-                K.conv_wgrad(prv["y"], dy, lay["gw"], lay["s"], self._am(0, j - 1), self._am(1, j), ln=(prv["stats"], prv["gamma"], prv["beta"]))
-            else:
-                x_in = self.images if j == 0 else prv["a"]
-                if f16:
-                    K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
+
+            def wgrad(dy=dy, j=j, lay=lay, prv=prv):
+                if prv is not None and prv.get("fused_now"):
+                    # the input activation was never written: the wgrad kernel applies LayerNorm + ELU to the producing layer's y
+                    K.conv_wgrad(prv["y"], dy, lay["gw"], lay["s"], self._am(0, j - 1), self._am(1, j), ln=(prv["stats"], prv["gamma"], prv["beta"]))
                 else:
-                    K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
+                    x_in = self.images if j == 0 else prv["a"]
+                    if f16:
+                        K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
+                    else:
+                        K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
+            if side is None:
+                wgrad()
+            else:
+                side.wait_stream(main)            # dy_j (and its amax word) are complete
+                with torch.cuda.stream(side):
+                    wgrad()
+                    if cur >= 0:
+                        reader_done[cur] = torch.cuda.Event()
+                        reader_done[cur].record(side)
             if not lay["has_ln"]:
                 # last conv: BiasAddGrad = column sums of dy (LN layers get theirs from ln_elu_bwd below)
                 K.colsum(dy.view(-1, lay["cout"]), lay["gb"], False)
@@ -247,7 +273,11 @@ class Trunk:
             prev = self.layers[j - 1]
             numel = prev["a"].numel()
             dA = self._dA[:numel].view(prev["out_shape"])
-            dYp = self._dY[:numel].view(prev["out_shape"])
+            nxt = (cur + 1) % len(dybufs)
+            if reader_done[nxt] is not None:      # the buffer LayerNorm backward is about to overwrite may still be read by a wgrad
+                main.wait_event(reader_done[nxt])
+                reader_done[nxt] = None
+            dYp = dybufs[nxt][:numel].view(prev["out_shape"])
             ws = lay["ws_bwd"] if (lay["ws_bwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
             if ws is not None or f16:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"] if ws is not None else 0)
@@ -261,4 +291,6 @@ class Trunk:
                              self._am(1, j - 1))
             else:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"])
-            dy = dYp
+            dy, cur = dYp, nxt
+        if side is not None:
+            main.wait_stream(side)                # every filter gradient is complete before the optimiser / all-reduce reads it

@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../scene-graph-gan_amd"
 mkdir -p _prof/$VARIANT
 pids=()
 for f in csrc/*.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=fast $DEF -I csrc -c $f -o _prof/$VARIANT/$(basename $f).o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=fast -Xclang -target-feature -Xclang -packed-fp32-ops $DEF -I csrc -c $f -o _prof/$VARIANT/$(basename $f).o  2> >(grep -v "not a recognized feature" >&2) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

@@ -1,0 +1,104 @@
+"""-m gpu: kernels of the path keep their results when another HIP stream runs MFMA kernels beside them.
+
+Found in round 2: with packed-fp32 VALU instructions (v_pk_fma_f32) in the library, conv_c3_fwd_kernel and
+conv_c3_wgrad_kernel returned wrong low halves in lanes 48-63 whenever conv_s2_kernel (or, rarely, conv_halo3_kernel) of ANOTHER
+stream shared their SIMD - 116 of 120 outputs differed; the single-stream schedule never shows it.  The library is built
+without packed-fp32 instructions (sgg_amd/build.py); this test keeps every kernel of a critic + generator step honest beside the
+heaviest MFMA kernels, and the two-stream schedule (GanStep(overlap_streams=True)) bit-equal to the serial one."""
+import pytest
+import torch
+
+import sgg_amd  # noqa: F401
+from oracle import sgg_oracle as O
+from sgg_amd.step import GanStep
+
+pytestmark = pytest.mark.gpu
+B, S, V = 8, 64, 50
+
+
+def _inputs():
+    images, labels, _ = O.synth_batch(B, S, V)
+    return (images.cuda(), labels.cuda(), O.synth_noise(B, 0).cuda(), O.synth_noise(B, 1).cuda(), O.synth_alpha(B, 0).reshape(B).cuda())
+
+
+def _new_step(hip, **kw):
+    gp, dp = O.init_params("G", V, S, perturb=0.05), O.init_params("D", V, S, perturb=0.05)
+    dp["W"] = dp["W"] * 25.0
+    return GanStep(hip, V, S, B, lam=10.0, g_state=gp, d_state=dp, **kw)
+
+
+def _snapshot(gs):
+    torch.cuda.synchronize()
+    out = {}
+    for n, net in (("G", gs.G), ("D", gs.D)):
+        for j, lay in enumerate(net.trunk.layers):
+            out["%s.y%d" % (n, j)] = lay["y"].clone()
+        for k, v in net.grads.items():
+            out["%s.grad.%s" % (n, k)] = v.clone()
+        out[n + ".weights"] = net.arena.flat.clone()
+    out["losses"] = torch.cat([gs.d_losses, gs.g_losses]).clone()
+    return out
+
+
+def test_step_is_unchanged_beside_mfma_kernels_of_another_stream(hip):
+    img, lab, noise0, noise1, alpha = _inputs()
+    side = torch.cuda.Stream()
+    agg = _new_step(hip)                       # an independent network: operands of the kernels that run beside
+    agg.critic_step(img, lab, noise0, alpha)
+    torch.cuda.synchronize()
+    T = agg.D.trunk
+
+    def conv(j, times):
+        lay = T.layers[j]
+        for _ in range(times):
+            hip.conv_fwd(T.layers[j - 1]["a"], lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], lay["ws_fwd"], T._am(0, j - 1), T._am(2, j),
+                         lay["tstats"], lay["ws_layout"])
+
+    def dgrad(j, times):
+        lay = T.layers[j]
+        dy, dx = torch.ones(lay["out_shape"], device="cuda"), torch.empty(lay["in_shape"], device="cuda")
+        for _ in range(times):
+            hip.conv_dgrad(dy, lay["w"], dx, lay["s"], lay["ws_bwd"], None, T._am(2, j), lay["ws_layout_bwd"])
+
+    assert T.layers[7]["ws_layout"] == 2 and T.layers[6]["ws_layout"] == 1
+
+    def run(beside):
+        gs = _new_step(hip)
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            beside()
+        gs.critic_step(img, lab, noise0, alpha)
+        gs.generator_step(img, noise1)
+        gs.flush()
+        overlapped = not side.query()          # the other stream was still busy when the step had been enqueued
+        return _snapshot(gs), overlapped
+
+    ref, _ = run(lambda: None)
+    for name, beside in (("conv_s2 forward", lambda: conv(7, 300)), ("conv_s2 dgrad", lambda: dgrad(7, 300)), ("conv_halo3 forward", lambda: conv(6, 300))):
+        for rep in range(4):
+            got, overlapped = run(beside)
+            assert overlapped, "the kernels beside finished before the step was enqueued: nothing was tested"
+            bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+            assert not bad, "beside %s (repetition %d) %d tensors differ, first %s" % (name, rep, len(bad), bad[:3])
+
+
+def test_two_stream_schedule_is_bitwise_the_serial_one(hip):
+    """overlap_streams=True (D's encoder beside G's forward; filter gradients beside the dgrad -> LayerNorm-backward chain) only
+    reorders independent launches: after two iterations of two critic updates each, every weight equals the serial run's."""
+    img, lab = _inputs()[:2]
+
+    def run(overlap):
+        gs = _new_step(hip, overlap_streams=overlap)
+        for it in range(2):
+            noises = [O.synth_noise(B, 10 * it + i).cuda() for i in range(3)]
+            alphas = [O.synth_alpha(B, 10 * it + i).reshape(B).cuda() for i in range(2)]
+            gs.train_iteration(img, lab, noises, alphas, critic_iters=2)
+        gs.flush()
+        return _snapshot(gs)
+
+    ref = run(False)
+    for rep in range(4):
+        got = run(True)
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, "repetition %d: %d tensors differ, first %s" % (rep, len(bad), bad[:3])

@@ -81,3 +81,4 @@ def test_gd_step_matches_oracle_config1(hip, scale_emb):
     print("min top-2 logit margin: %.3e" % margin)
     assert margin > 1e-4, "seed gives an argmax margin inside the fp tolerance"
     assert torch.equal(toks, O.argmax_tokens(gaux["fake"]))
+

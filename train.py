@@ -39,7 +39,7 @@ class SceneGraphGAN(object):
     ############################################################
     def __init__(self, checkpoints_dir, summaries_dir, path_to_ims_to_triples, path_to_vocab, path_to_word_embeddings,
                  path_to_image_means, path_to_image_stds, critic_iters, batch_size, lambda_, resume,
-                 synthetic=None, device=None, seed=0):
+                 synthetic=None, device=None, seed=0, two_streams=True):
         # Hyperparameters (train.py:26-32)
         self.CRITIC_ITERS = int(critic_iters)
         self.BATCH_SIZE = int(batch_size)
@@ -48,6 +48,9 @@ class SceneGraphGAN(object):
         self.TEST_BATCH_MULTIPLIER = 8
         self.LAMBDA = float(lambda_)
         self.resume = bool(resume)
+        # two-stream schedule of step.GanStep (D's encoder beside G's forward, filter gradients beside the dgrad -> LayerNorm
+        # chain): same kernels, bit-identical results (tests/test_concurrency_gpu.py), +4 % triples/s
+        self.two_streams = bool(two_streams)
         self.checkpoints_dir, self.summaries_dir = checkpoints_dir, summaries_dir
         self.rank, self.world, local = dpmod.init_from_env()
         self.device = torch.device(device if device is not None else "cuda:%d" % local)
@@ -170,7 +173,8 @@ class SceneGraphGAN(object):
         B, S, V = images.shape[0], images.shape[1], len(self.vocab)
         g_net, d_net = self.g._ensure(images), self.d._ensure(images)
         reducer = dpmod.GradReducer() if self.world > 1 else None
-        self.step = GanStep(kernels_for(self.device), V, S, B, lam=self.LAMBDA, G=g_net, D=d_net, reducer=reducer)
+        self.step = GanStep(kernels_for(self.device), V, S, B, lam=self.LAMBDA, G=g_net, D=d_net, reducer=reducer,
+                            overlap_streams=self.two_streams)
 
     def train(self, max_iterations=None, log_every=10, save_every=0):
         images, labels = self._next_batch(0)
@@ -290,6 +294,7 @@ if __name__ == "__main__":
     parser.add_argument("--GPU", default="0", help="Which GPU to use (single-process runs)")
     parser.add_argument("--synthetic", default=None, help="B,S,V: train on synthetic tensors of that shape (no dataset files)")
     parser.add_argument("--max_iterations", default=None, type=int)
+    parser.add_argument("--single_stream", action="store_true", help="serial launch order (default: two HIP streams)")
     args = parser.parse_args()
     params = vars(args)
 
@@ -301,5 +306,5 @@ if __name__ == "__main__":
                         path_to_word_embeddings=params["path_to_word_embeddings"],
                         path_to_image_means=params["path_to_image_means"], path_to_image_stds=params["path_to_image_stds"],
                         critic_iters=params["critic_iters"], batch_size=params["batch_size"], lambda_=params["lambda"],
-                        resume=params["resume"], synthetic=synthetic)
+                        resume=params["resume"], synthetic=synthetic, two_streams=not params["single_stream"])
     gan.train(max_iterations=params["max_iterations"])
