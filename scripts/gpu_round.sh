@@ -16,11 +16,11 @@ case $STEP in
     tail -5 $O/pytest_gpu.log ;;
   bench)
     timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
-    cat $O/bench.json ;;
+    head -c 400 $O/bench.json ;;
   configs34)
     timeout -k 10 500 python bench.py --config 3 > $O/bench_config3.json 2> $O/bench_config3.err || { tail -20 $O/bench_config3.err; exit 1; }
     timeout -k 10 500 python bench.py --config 4 > $O/bench_config4.json 2> $O/bench_config4.err || { tail -20 $O/bench_config4.err; exit 1; }
-    cat $O/bench_config3.json $O/bench_config4.json ;;
+    head -c 300 $O/bench_config3.json; echo; head -c 300 $O/bench_config4.json ;;
   stats)
     cd /tmp && export TMPDIR=/tmp
     timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 --f32-steps 0 --ci10-steps 0 --two-stream-steps 0 > $O/bench_under_rocprof.json 2> $O/stats.err
