@@ -9,7 +9,7 @@ git -C "$ROOT" archive "$REV" scene-graph-gan_amd/csrc | tar -x -C "$TMP"
 cd "$TMP/scene-graph-gan_amd"
 pids=()
 for f in csrc/*.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=fast -I csrc -c "$f" -o "$(basename "$f").o" &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=fast -Xclang -target-feature -Xclang -packed-fp32-ops -I csrc -c "$f" -o "$(basename "$f").o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done      # a failed compile aborts the script here (set -e)
