@@ -39,9 +39,12 @@ struct WgradHaloPlan {
   int nsplit;           // workgroups along the pixel dimension
   int stages;           // stages per workgroup
   int nslabs;           // nsplit * spw
+  int geo;              // 0: 8x8 pixel blocks;  1: row bands (R full-width rows, up to 112 pixels) for grids that 8x8 blocks do not tile
+  int R, pc, xslots;    // geo 1: rows per band, patch pitch (W + 1: one shared zero column), patch slots ((R + 2) * pc + 1)
   size_t ws_bytes;
 };
-// returns 1 and fills the plan if the shape is served (H, W = the dy grid, both % 8 == 0; 3x3 stride 1 or 5x5 stride 2; channels % 32 == 0)
+// returns 1 and fills the plan if the shape is served (H, W = the dy grid; 3x3 stride 1 or 5x5 stride 2; channels % 32 == 0;
+// H % 8 == W % 8 == 0, or - channels % 64 == 0 - any H with W <= 28: row bands)
 int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradHaloPlan* pl);
 // writes pl.nslabs partial dW slabs [slab][9][Cin][Cout] (unscaled f32) into `slabs`
 void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,

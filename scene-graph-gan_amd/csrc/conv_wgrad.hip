@@ -628,7 +628,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   const long long nout = (long long)KH * KW * Cin * Cout;
   WgradHaloPlan hp;
   if ((precision == 2 || precision == 3) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho * stride && Wi == Wo * stride &&
-      algo == 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp)) {
+      algo == 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp) && !(hp.geo == 1 && ln_stats)) {
     // halo-resident kernel: the nine taps of a channel chunk from one LDS-resident patch (conv_wgrad_halo.hip)
     if (!workspace || workspace_bytes < hp.ws_bytes) {
       sgg_set_error("sgg_conv2d_nhwc_wgrad: workspace too small (%zu < %zu)", workspace_bytes, hp.ws_bytes);

@@ -14,8 +14,15 @@
 // offset on one base register (no per-tap address arithmetic at all).  Rows are 64 B (32 channels) and a 32-lane
 // phase of the read covers 4 consecutive pixel slots = 256 contiguous bytes: conflict free without a swizzle.
 // Partial sums go to f32 slabs [slab][9][Cin][Cout] summed in fixed order by slab_reduce_kernel (deterministic).
+//
+// GEO = 1 (row bands): 28x28 and 14x14 grids (conv3_5, `downsampled`) are not tiled by 8x8 blocks.  There a block is R FULL-WIDTH
+// rows of one image with R * W <= 112 pixels (seven 16-pixel MFMA steps: 4 x 28, 8 x 14), the patch is (R + 2) rows of pitch W + 1:
+// both halo columns of a full-width band are zero padding, so one zero slot per row serves as the right halo of row r and the left
+// halo of row r + 1.  A lane's pixel of a k-step is pid = 16 ks + 8 (g >> 1) + q (+ 4), its patch slot ((pid / W) * (W + 1) +
+// pid % W), tap shifts are run-time slot offsets.  73.5 KB of LDS per workgroup (gfx950 gives a workgroup up to 160 KB).
 #include "split16.h"
 #include "conv_halo.h"
+#include <type_traits>
 
 typedef short s16x4h __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
@@ -41,7 +48,10 @@ struct WgradHaloParams {
   int a0y, a0x;           // first sub-grid offset of the class's taps (-1 or 0): tap (ia, ib) reads sub-grid pixel (oy + a0y + ia, ox + a0x + ib)
   int kh0, kw0, kstep;    // kernel tap of (ia, ib) = (kh0 + kstep*ia, kw0 + kstep*ib)
   int KWt, taps_total;    // kernel width (3 / 5) and KH*KW: slab layout [slab][taps_total][Cin][Cout]
-  int bh, bw, nblk;       // 8x8 blocks per image (rows, cols) and in total
+  int bh, bw, nblk;       // 8x8 blocks per image (rows, cols) and in total (GEO 1: bands per image, 1)
+  int R, pc, xslots, npx; // GEO 1: rows per band, patch pitch, patch slots, pixels of a full band (R * W)
+  unsigned magic_w;       // GEO 1: ceil(2^32 / W) for pid / W (pid < 112)
+  unsigned magic_pc;      // GEO 1: ceil(2^32 / pc) for slot / pc (slot < 176)
   int pairs_n;            // Cout chunks
   int stages;             // stages per workgroup (NBS blocks each)
   unsigned x_bytes, dy_bytes;
@@ -49,20 +59,26 @@ struct WgradHaloParams {
 
 // NKH x NKW: taps of the launch (3x3 for the stride-1 kernel; 3x3 / 3x2 / 2x3 / 2x2 for the four parity classes of a 5x5
 // stride-2 kernel, each a stride-1 problem on the sub-sampled x grid).
-template <int CT, int NT, bool HALF, bool PREF, int NKH, int NKW, bool LNP>
+template <int CT, int NT, bool HALF, bool PREF, int NKH, int NKW, bool LNP, int GEO = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParams p) {
+  static_assert(GEO == 0 || (CT == 2 && NT == 2 && !LNP), "row bands: 64 x 64 channel chunks only");
   constexpr int NTAP = NKH * NKW;
   constexpr int P = 2;
   constexpr int NBS = (CT == 2) ? 1 : 2;                 // blocks per stage
-  constexpr int KSW = (CT == 1 && NT == 1) ? 2 : 4;      // 16-pixel MFMA steps per wave and block
+  constexpr int KSW = GEO ? 7 : ((CT == 1 && NT == 1) ? 2 : 4);      // 16-pixel MFMA steps per wave and block
   constexpr int SPW = 4 / (CT * NT) ;                    // waves that share a channel tile (own slabs)
-  constexpr int XSUB = 120 * 64;                         // bytes of one 32-channel sub-plane of a block's patch (10 x pitch 12)
+  constexpr int XSLOTS = GEO ? 176 : 120;                // patch slots of a block (GEO 0: 10 x pitch 12)
+  constexpr int XSUB = XSLOTS * 64;                      // bytes of one 32-channel sub-plane of a block's patch
   constexpr int XPLANE = NBS * CT * XSUB;
-  constexpr int DSUB = 64 * 64;
+  constexpr int DPX = GEO ? 112 : 64;                    // dy pixels of a block
+  constexpr int DSUB = DPX * 64;
   constexpr int DPLANE = NBS * NT * DSUB;
-  constexpr int XI = 400 * CT, XP = (XI + 255) / 256;    // x staging items (patch pixel, 8 channels) per block, passes
-  constexpr int DI = 256 * NT, DP = DI / 256;
+  constexpr int XI = (GEO ? XSLOTS * 4 : 400) * CT, XP = (XI + 255) / 256;    // x staging items (patch pixel, 8 channels) per block, passes
+  constexpr int DI = DPX * 4 * NT, DP = (DI + 255) / 256;
   constexpr int NPASS = NBS * (XP + DP);
+  // GEO 1 with nine taps: 144 accumulator registers leave room for the x prefetch only; dy is loaded after the MFMAs of a stage
+  // (the other resident workgroup computes meanwhile)
+  constexpr bool DY_LATE = GEO == 1 && NTAP > 6;
   __shared__ __attribute__((aligned(16))) unsigned char lds[P * (XPLANE + DPLANE)];
   __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 64 * CT : 4];   // gamma, beta of this workgroup's 32*CT input channels
   unsigned char* x_s = lds;
@@ -87,10 +103,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   const float sa = ldexpf(1.f, ea), sb = ldexpf(1.f, eb);
 
   // ---- staging plan: pass -> (kind, block); item -> offset relative to the block origin, border bits, LDS offset ----
-  unsigned it_rel[NPASS];
-  int it_lds[NPASS];        // bits 0..19 LDS byte offset inside a plane, bits 20..23 border bits, bit 24 valid
+  // GEO 1: the plan of an item is recomputed where it is used (20 registers less than keeping it)
+  //   meta bits 0..19 LDS byte offset, 20..24 patch row (x) / 20..26 pixel (dy), 27 zero column, 28 valid
+  auto rb_plan = [&](int jj, unsigned& rel, int& meta) __attribute__((always_inline)) {
+    if (jj < XP) {
+      const int i = tid + 256 * jj;
+      const int csub = i >= XSLOTS * 4 ? 1 : 0, r = i - csub * (XSLOTS * 4);
+      const int slot = r >> 2, c4 = r & 3;
+      const int ry = (int)__umulhi((unsigned)slot, p.magic_pc), rx = slot - ry * p.pc;
+      rel = (unsigned)(((ry * p.sxy * p.Wx + rx * p.sxy) * p.C + csub * 32 + c4 * 8) * 4);
+      meta = (csub * XSUB + slot * 64 + c4 * 16) | (ry << 20) | ((rx == 0) << 27) | ((i < XI && slot < p.xslots) << 28);
+    } else {
+      const int i = tid + 256 * (jj - XP);
+      const int nsub = i >= DPX * 4 ? 1 : 0, r = i - nsub * (DPX * 4);
+      const int px = r >> 2, c4 = r & 3;
+      rel = (unsigned)((px * p.N + nsub * 32 + c4 * 8) * 4);
+      meta = (nsub * DSUB + px * 64 + c4 * 16) | (px << 20) | ((i < DI) << 28);
+    }
+  };
+  unsigned it_rel[GEO ? 1 : NPASS];
+  int it_lds[GEO ? 1 : NPASS];        // bits 0..19 LDS byte offset inside a plane, bits 20..23 border bits, bit 24 valid
 #pragma unroll
-  for (int j = 0; j < NPASS; ++j) {
+  for (int j = 0; j < (GEO ? 0 : NPASS); ++j) {
     const int blk = j / (XP + DP), jj = j % (XP + DP);
     if (jj < XP) {
       const int i = tid + 256 * jj;
@@ -132,7 +166,65 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   float ld_mu[NBS], ld_rs[NBS];    // LN prologue: (mean, rstd) of the staged blocks' samples, padding items of the patch in flight
   int ld_bad = 0;
 
-  f32x4 pre[NPASS][2];
+  f32x4 pre[DY_LATE ? XP : NPASS][2];
+  // GEO 1 staging (one band per stage).  part 0: x patch and dy band; 1: x patch only; 2: dy band only (into pre[0..DP)).  The
+  // block cursor advances once both parts of a band have been issued.
+  auto stage_load_rb = [&](auto part_c) __attribute__((always_inline)) {
+    constexpr int part = decltype(part_c)::value;
+    const bool dead = (next_beta >= p.nblk) | (next_beta >= blk_begin + p.stages);
+    const int r0 = cy[0] * p.R;
+    const int rows_left = p.H - r0;                                  // sub-grid rows from r0 to the end of the image
+    const int npx_valid = (rows_left < p.R ? rows_left : p.R) * p.W;
+    const unsigned xbase = (unsigned)((((cb[0] * p.Hx + (r0 - 1) * p.sxy + p.cy) * p.Wx - p.sxy + p.cx) * p.C + c0) * 4);
+    const unsigned dbase = (unsigned)((((cb[0] * p.H + r0) * p.W) * p.N + n0) * 4);
+#pragma unroll
+    for (int jj = 0; jj < XP + DP; ++jj) {
+      const bool isx = jj < XP;
+      if ((part == 1 && !isx) || (part == 2 && isx)) continue;
+      unsigned rel;
+      int meta;
+      rb_plan(jj, rel, meta);
+      bool bad = dead | !((meta >> 28) & 1);
+      if (isx) {
+        const int ry = (meta >> 20) & 31;
+        bad |= ((meta >> 27) & 1) | ((ry == 0) & (r0 == 0)) | (ry > rows_left);
+      } else {
+        bad |= ((meta >> 20) & 127) >= npx_valid;
+      }
+      const unsigned off = bad ? SGG_OOB : (isx ? xbase : dbase) + rel;
+      const int slot = (DY_LATE && !isx) ? jj - XP : jj;
+      if (isx) {
+        pre[slot][0] = buf_load4(rs_x, off);
+        pre[slot][1] = buf_load4(rs_x, off + 16u);
+      } else {
+        pre[slot][0] = buf_load4(rs_dy, off);
+        pre[slot][1] = buf_load4(rs_dy, off + 16u);
+      }
+    }
+    if constexpr (part != 1) {
+      if (++cy[0] >= p.bh) { cy[0] = 0; ++cb[0]; }
+      next_beta += 1;
+    }
+  };
+  auto stage_write_rb = [&](auto part_c) __attribute__((always_inline)) {
+    constexpr int part = decltype(part_c)::value;
+#pragma unroll
+    for (int jj = 0; jj < XP + DP; ++jj) {
+      const bool isx = jj < XP;
+      if ((part == 1 && !isx) || (part == 2 && isx)) continue;
+      const int slot = (DY_LATE && !isx) ? jj - XP : jj;
+      u32x4 pl[P];
+      split8<P, HALF>(pre[slot][0], pre[slot][1], isx ? sa : sb, pl);
+      unsigned rel;
+      int meta;
+      rb_plan(jj, rel, meta);
+      if ((meta >> 28) & 1) {
+        unsigned char* dst = (isx ? x_s : d_s) + (meta & 0xfffff);
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * (isx ? XPLANE : DPLANE)) = pl[pp];
+      }
+    }
+  };
   auto stage_load = [&]() {
 #pragma unroll
     for (int blk = 0; blk < NBS; ++blk) {
@@ -196,8 +288,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   // lane 4q+pch of the group addresses pixel q (lo) / q+4 (hi) of the k half's row and channels 4pch..4pch+3
   const int g = lane >> 4, q = (lane >> 2) & 3, pch = lane & 3;
   const int choff = ((g & 1) * 2 + (pch >> 1)) * 16 + (pch & 1) * 8;
-  const unsigned char* a_base = x_s + (wblk * CT + ci_t) * XSUB + ((2 * ks0 + (g >> 1) + p.a0y + 1) * 12 + q + p.a0x + 1) * 64 + choff;
+  const unsigned char* a_base = x_s + (wblk * CT + ci_t) * XSUB + (GEO ? ((p.a0y + 1) * p.pc + p.a0x + 1) * 64 : ((2 * ks0 + (g >> 1) + p.a0y + 1) * 12 + q + p.a0x + 1) * 64) + choff;
   const unsigned char* b_base = d_s + (wblk * NT + co_t) * DSUB + ((2 * ks0 + (g >> 1)) * 8 + q) * 64 + choff;
+  // GEO 1: byte offset of pixel pid's patch slot relative to a_base (pixels past the band: clamped, their dy is zero)
+  auto rb_slot = [&](int pid) __attribute__((always_inline)) {
+    pid = pid < p.npx ? pid : p.npx - 1;
+    const int row = (int)__umulhi((unsigned)pid, p.magic_w);
+    return (row * p.pc + (pid - row * p.W)) * 64;
+  };
 
   f32x16 acc[NTAP];
 #pragma unroll
@@ -205,7 +303,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  auto compute = [&]() {
+  auto compute = [&]() __attribute__((always_inline)) {
+    if constexpr (GEO == 1) {
+      // (not unrolled over the seven k-steps: the per-step patch addresses are run-time values; unrolled they are hoisted and spilled)
+      const int pc64 = p.pc * 64;
+#pragma unroll 1
+      for (int ksi = 0; ksi < KSW; ++ksi) {
+        u32x4 b[P];
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+          const u32x2h lo = lds_tr16(b_base + ksi * 1024 + pp * DPLANE);
+          const u32x2h hi = lds_tr16(b_base + ksi * 1024 + 256 + pp * DPLANE);
+          b[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        const int pid = 16 * ksi + 8 * (g >> 1) + q;
+        const unsigned char* alo = a_base + rb_slot(pid);
+        const unsigned char* ahi = a_base + rb_slot(pid + 4);
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+          const int kh = tap / NKW, kw = tap % NKW;
+          u32x4 a[P];
+#pragma unroll
+          for (int pp = 0; pp < P; ++pp) {
+            const u32x2h lo = lds_tr16(alo + kh * pc64 + kw * 64 + pp * XPLANE);
+            const u32x2h hi = lds_tr16(ahi + kh * pc64 + kw * 64 + pp * XPLANE);
+            a[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
+          f32x16 d = acc[tap];
+          d = mfma16<HALF>(a[1], b[0], d);
+          d = mfma16<HALF>(a[0], b[1], d);
+          d = mfma16<HALF>(a[0], b[0], d);
+          acc[tap] = d;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ksi = 0; ksi < KSW; ++ksi) {
       u32x4 b[P];
@@ -234,6 +366,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
     }
   };
 
+  if constexpr (GEO == 1) {
+    // x patch of the next band prefetched under the MFMAs; with late dy its band is loaded and written after them
+    auto load1 = [&]() __attribute__((always_inline)) { stage_load_rb(std::integral_constant<int, DY_LATE ? 1 : 0>{}); };
+    auto write1 = [&]() __attribute__((always_inline)) {
+      if constexpr (DY_LATE) {
+        stage_write_rb(std::integral_constant<int, 1>{});
+        stage_load_rb(std::integral_constant<int, 2>{});
+        stage_write_rb(std::integral_constant<int, 2>{});
+      } else {
+        stage_write_rb(std::integral_constant<int, 0>{});
+      }
+    };
+    load1();
+    write1();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < p.stages; ++s) {
+      load1();
+      __builtin_amdgcn_sched_barrier(0);
+      compute();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      write1();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
   stage_load();
   stage_write();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -248,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
     stage_write();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
   }
 
   // ---- partial slab: [slab][tap][Cin][Cout] -------------------------------------------------------------------
@@ -269,9 +429,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
 // (1, 2)); H % 8 == W % 8 == 0, channels % 32 == 0.
 int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradHaloPlan* pl) {
   const bool k3 = KH == 3 && KW == 3 && stride == 1, k5 = KH == 5 && KW == 5 && stride == 2;
-  if (!((k3 || k5) && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cin % 32 == 0 && Cout % 32 == 0 && B > 0)) return 0;
+  if (!((k3 || k5) && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 32 == 0 && B > 0)) return 0;
   if ((size_t)B * H * W * stride * stride * Cin * sizeof(float) >= 0x80000000ull || (size_t)B * H * W * Cout * sizeof(float) >= 0x80000000ull)
     return 0;
+  pl->geo = 0; pl->R = 8; pl->pc = 12; pl->xslots = 120;
+  if (H % 8 != 0 || W % 8 != 0) {
+    // row bands: R full-width rows with R * W <= 112 pixels and a patch of (R + 2) * (W + 1) + 1 <= 176 slots; 64 x 64 channel chunks
+    int R = 112 / W;
+    if (R > H) R = H;
+    while (R > 0 && (R + 2) * (W + 1) + 1 > 176) --R;
+    if (R < 1 || Cin % 64 != 0 || Cout % 64 != 0) return 0;
+    pl->geo = 1; pl->R = R; pl->pc = W + 1; pl->xslots = (R + 2) * (W + 1) + 1;
+  }
   if (Cin % 64 == 0 && Cout % 64 == 0) { pl->ct = 2; pl->nt = 2; }
   else if (Cout % 64 == 0) { pl->ct = 1; pl->nt = 2; }
   else { pl->ct = 1; pl->nt = 1; }
@@ -279,7 +448,7 @@ int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, 
   pl->spw = 4 / (pl->ct * pl->nt);
   pl->pairs_n = Cout / (32 * pl->nt);
   pl->pairs = (Cin / (32 * pl->ct)) * pl->pairs_n;
-  const int nblk = B * (H / 8) * (W / 8);
+  const int nblk = pl->geo ? B * ((H + pl->R - 1) / pl->R) : B * (H / 8) * (W / 8);
   const int total_stages = (nblk + pl->nbs - 1) / pl->nbs;
   int ns = 512 / pl->pairs;                       // one resident round of 2 workgroups per CU
   if (ns > total_stages / 8) ns = total_stages / 8;
@@ -294,6 +463,11 @@ int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, 
 template <int NKH, int NKW>
 static void wgrad_halo_launch_class(const WgradHaloParams& p, const WgradHaloPlan& pl, bool half, hipStream_t st) {
   const dim3 grid(pl.nsplit, pl.pairs);
+  if (pl.geo == 1) {   // row bands (64 x 64 channel chunks, no LN prologue: host checks)
+    if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<2, 2, true, true, NKH, NKW, false, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<2, 2, false, true, NKH, NKW, false, 1>), grid, dim3(256), 0, st, p);
+    return;
+  }
 #define SGG_WH(CT, NT, PF)                                                                                          \
   do {                                                                                                              \
     if (p.ln_stats) {                                                                                               \
@@ -316,6 +490,9 @@ void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B,
   p.x = x; p.dy = dy; p.slabs = slabs; p.amax_x = amax_x; p.amax_dy = amax_dy;
   p.ln_stats = ln_stats; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.B = B;
   p.H = H; p.W = W; p.C = Cin; p.N = Cout; p.bh = H / 8; p.bw = W / 8; p.nblk = B * p.bh * p.bw;
+  p.R = pl.R; p.pc = pl.pc; p.xslots = pl.xslots; p.npx = pl.R * W; p.magic_w = (unsigned)((0x100000000ull + W - 1) / W);
+  p.magic_pc = (unsigned)((0x100000000ull + pl.pc - 1) / pl.pc);
+  if (pl.geo == 1) { p.bh = (H + pl.R - 1) / pl.R; p.bw = 1; p.nblk = B * p.bh; }
   p.Hx = H * stride; p.Wx = W * stride; p.sxy = stride;
   p.pairs_n = pl.pairs_n; p.stages = pl.stages;
   p.x_bytes = (unsigned)((size_t)B * p.Hx * p.Wx * Cin * sizeof(float));

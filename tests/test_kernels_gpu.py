@@ -54,6 +54,12 @@ CONV_CASES = [
     (2, 32, 16, 32, 64, 5, 2),
     (3, 16, 32, 64, 128, 5, 2),
     (1, 16, 16, 128, 128, 5, 2),
+    # wgrad in row bands (grids that 8x8 blocks do not tile, 64+ channels): 28x28 in 4-row bands, 14x14 in 8-row bands, 12x20 in
+    # bands of 5, 5 and 2 rows, 7x7 as one band; the 3x3 cases above with 20x20, 9x9 and 6x6 grids take the same path
+    (2, 56, 56, 64, 128, 5, 2),
+    (3, 28, 28, 128, 64, 5, 2),
+    (2, 24, 40, 64, 64, 5, 2),
+    (1, 14, 14, 64, 64, 5, 2),
 ]
 
 
