@@ -47,7 +47,13 @@ int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; ze
  * forward, the HWIO kernel for dgrad) and w_split_layout = 1 is passed to sgg_conv2d_nhwc_fwd / _dgrad.  Layout 0 = planes.
  * Band-resident kernel for the 5x5 stride-2 layers (generator_with_attention.py:35,50,65,68: conv2_5, conv3_5, `downsampled`;
  * conv1_3 has too few channels for its 128-column tile) on even grids: sgg_conv_wsplit_layout returns 2 (H, W = the full-resolution
- * grid; ask with (Cin, Cout) swapped for the dgrad direction); weights in the same fragment order with taps = 25. */
+ * grid; ask with (Cin, Cout) swapped for the dgrad direction); weights in the same fragment order with taps = 25.
+ * conv1_3 (generator_with_attention.py:35: 5x5 stride 2 over 32 -> 32 channels, H % 16 == W % 16 == 0): sgg_conv_wsplit_layout
+ * returns 3 - the convolution runs on the halo-resident kernel as a 3x3 stride-1 convolution over the space-to-depth view of x
+ * (x[2a + qy][2c + qx][ci] = channel (qy, qx, ci) of pixel (a, c); no copy, strides only) with the 9-tap kernel
+ * [3][3][4 * Cin][Cout] of sgg_conv_s2d_weights (11 of its 36 (tap, parity) slots are zero); weights in fragment order with
+ * taps = 9 (forward: the HWOI transpose of that kernel, N = Cout, C = 4 * Cin; dgrad: the kernel itself, N = 4 * Cin, C = Cout). */
+int sgg_conv_s2d_weights(const float* w5 /* [5][5][Cin][Cout] */, float* w3 /* [3][3][4*Cin][Cout] */, int Cin, int Cout, void* stream);
 /* The library reads no environment variables and keeps no mutable global state: every kernel choice is a function of the
  * arguments (w_split_layout here, `algo` of sgg_conv2d_nhwc_wgrad). */
 int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);

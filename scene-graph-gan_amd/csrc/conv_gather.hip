@@ -795,6 +795,10 @@ extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout,
     if (!sgg_s2_applicable(KH, KW, stride, 1, 2 * Ho, 2 * Wo, Cin, Cout, precision)) return 0;
     return sgg_s2_stats_per_sample(Ho, Wo, Cout);
   }
+  if (w_split_layout == 3) {
+    if (!sgg_s2d_applicable(KH, KW, stride, 2 * Ho, 2 * Wo, Cin, Cout, precision)) return 0;
+    return (Ho * Wo / 64) * (Cout / sgg_halo_stats_cols(Cout));
+  }
   const int bm = (Cout % 128 == 0) ? 128 : 256;
   const int bn = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0 ? 64 : 32);
   if ((Ho * Wo) % bm != 0) return 0;
@@ -836,9 +840,27 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     h.B = B; h.H = Hi; h.W = Wi; h.C = Cin; h.N = Cout; h.bh = Hi / 8; h.bw = Wi / 8; h.nblk = B * h.bh * h.bw; h.flip = 0;
     h.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
+    sgg_halo_dense_strides(h);
     SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(halo)");
+    return SGG_OK;
+  }
+  if (w_split_layout == 3) {        // 5x5 stride 2 over 32 channels = 3x3 stride 1 over the space-to-depth view of x (halo-resident kernel)
+    SGG_CHECK_ARG(w_split && sgg_s2d_applicable(KH, KW, stride, Hi, Wi, Cin, Cout, precision) && pad_t == 1 && pad_l == 1,
+                  "sgg_conv2d_nhwc_fwd: w_split_layout 3 needs 5x5 stride 2, 32 -> 32 channels, H %% 16 == W %% 16 == 0, precision 2 or 3 "
+                  "(sgg_conv_wsplit_layout)");
+    SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
+    HaloParams h;
+    h.src = x; h.wfrag = w_split; h.bias = bias; h.out = y; h.amax_src = amax_x; h.amax_w = amax_w; h.tile_stats = tile_stats;
+    h.ln_stats = nullptr; h.ln_gamma = nullptr; h.ln_beta = nullptr;
+    h.B = B; h.H = Ho; h.W = Wo; h.C = 4 * Cin; h.N = Cout; h.bh = Ho / 8; h.bw = Wo / 8; h.nblk = B * h.bh * h.bw; h.flip = 0;
+    h.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
+    h.w_bytes = (unsigned)((size_t)9 * 4 * Cin * Cout * sizeof(float));
+    sgg_halo_dense_strides(h);
+    h.in_rs = 2 * Wi * Cin; h.in_ps = 2 * Cin; h.in_cA = Wi * Cin; h.in_cB = Cin;     // chunk (qy, qx): x[2a + qy][2c + qx][0..32)
+    sgg_halo_launch(h, precision, st);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(s2d)");
     return SGG_OK;
   }
   if (w_split_layout == 2) {        // band-resident 5x5 stride-2 kernel (conv_s2.hip), weights in MFMA fragment order (25 taps)
@@ -901,8 +923,26 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     h.B = B; h.H = Hi; h.W = Wi; h.C = Cout; h.N = Cin; h.bh = Hi / 8; h.bw = Wi / 8; h.nblk = B * h.bh * h.bw; h.flip = 1;
     h.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
+    sgg_halo_dense_strides(h);
     sgg_halo_launch(h, precision, (hipStream_t)stream);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(halo)");
+    return SGG_OK;
+  }
+  if (w_split_layout == 3) {        // dx through the space-to-depth view: 3x3 correlation of dy with the mirrored 9-tap kernel, 4*Cin outputs
+    SGG_CHECK_ARG(w_split && sgg_s2d_applicable(KH, KW, stride, Hi, Wi, Cin, Cout, precision) && pad_t == 1 && pad_l == 1 &&
+                      Hi == 2 * Ho && Wi == 2 * Wo,
+                  "sgg_conv2d_nhwc_dgrad: w_split_layout 3 needs 5x5 stride 2, 32 -> 32 channels, H %% 16 == W %% 16 == 0, precision 2 or 3 "
+                  "(sgg_conv_wsplit_layout)");
+    HaloParams h;
+    h.src = dy; h.wfrag = w_split; h.bias = nullptr; h.out = dx; h.amax_src = amax_dy; h.amax_w = amax_w; h.tile_stats = nullptr;
+    h.ln_stats = nullptr; h.ln_gamma = nullptr; h.ln_beta = nullptr;
+    h.B = B; h.H = Ho; h.W = Wo; h.C = Cout; h.N = 4 * Cin; h.bh = Ho / 8; h.bw = Wo / 8; h.nblk = B * h.bh * h.bw; h.flip = 1;
+    h.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
+    h.w_bytes = (unsigned)((size_t)9 * 4 * Cin * Cout * sizeof(float));
+    sgg_halo_dense_strides(h);
+    h.out_rs = 2 * Wi * Cin; h.out_ps = 2 * Cin; h.out_nA = Wi * Cin; h.out_nB = Cin;  // group (qy, qx) -> dx[2a + qy][2c + qx][0..32)
+    sgg_halo_launch(h, precision, (hipStream_t)stream);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(s2d)");
     return SGG_OK;
   }
   if (w_split_layout == 2) {        // band-resident 5x5 stride-2 kernel: the four pixel parities of dx from resident dy patches

@@ -22,10 +22,21 @@ struct HaloParams {
   int flip;               // 0: forward (correlation); 1: dgrad (taps mirrored)
   unsigned src_bytes, w_bytes;
   int gx;                 // workgroups per XCD (set by sgg_halo_launch)
+  // Addressing in floats (sgg_halo_dense_strides fills the NHWC defaults).  Source: grid row / pixel strides and the offset of
+  // 32-channel chunk cc = (cc >> 1) * in_cA + (cc & 1) * in_cB; output: the same for 32-column group g.  A 5x5 stride-2
+  // convolution over 32 channels runs here as a 3x3 stride-1 convolution over the SPACE-TO-DEPTH view of x (chunk = pixel parity
+  // (qy, qx): row stride 2*Wx*32, pixel stride 64, cA = Wx*32, cB = 32), its dgrad writes dx through the same view.
+  int in_rs, in_ps, in_cA, in_cB;
+  int out_rs, out_ps, out_nA, out_nB;
 };
+inline void sgg_halo_dense_strides(HaloParams& h) {
+  h.in_rs = h.W * h.C; h.in_ps = h.C; h.in_cA = 64; h.in_cB = 32;
+  h.out_rs = h.W * h.N; h.out_ps = h.N; h.out_nA = 64; h.out_nB = 32;
+}
 
 // 1 if the halo kernel serves a 3x3 / stride-1 convolution over an H x W grid in this precision
 int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, int precision);
+int sgg_s2d_applicable(int KH, int KW, int stride, int Hi, int Wi, int Cin, int Cout, int precision);
 // columns covered by one (count, mean, M2) partial of the halo kernel for N output channels
 int sgg_halo_stats_cols(int N);
 void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st);

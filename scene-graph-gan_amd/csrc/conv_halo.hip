@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     const int blk = it / 400, r = it % 400;
     const int px = r >> 2, ch8 = r & 3;
     const int ry = px / 10, rx = px % 10;
-    it_rel[j] = (unsigned)(((ry * p.W + rx) * p.C + ch8 * 8) * 4);
+    it_rel[j] = (unsigned)((ry * p.in_rs + rx * p.in_ps + ch8 * 8) * 4);
     const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
     it_meta[j] = (blk * HALO_BLKB + (ry * HALO_PITCH + rx) * 64 + ((ch8 ^ halo_sw(ry, rx)) << 4)) | (bits << 20) | ((blk & 3) << 24) |
                  (ch8 << 26) | ((it < ITEMS) << 28);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const bool dead = (s_tile >= mt_end) | (s_tile * NB + j >= p.nblk);
-      base[j] = (unsigned)((((s_grow[j] * 8 - 1) * p.W + s_bx[j] * 8 - 1) * p.C + s_cc * 32) * 4);
+      base[j] = (unsigned)(((s_grow[j] * 8 - 1) * p.in_rs + (s_bx[j] * 8 - 1) * p.in_ps + (s_cc >> 1) * p.in_cA + (s_cc & 1) * p.in_cB) * 4);
       bbits[j] = dead ? 15 : ((s_by[j] == 0) | ((s_by[j] == p.bh - 1) << 1) | ((s_bx[j] == 0) << 2) | ((s_bx[j] == p.bw - 1) << 3));
       // a dead block: every item masked (bits 0 -> use the valid flag below)
       if (dead) base[j] = SGG_OOB;
@@ -330,13 +330,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     o_grow = beta / p.bw;
     o_bx = beta % p.bw;
   }
-  const unsigned o_lane_b = (unsigned)((4 * h * p.N) + n0 + wn0 + (lane & 31)) * 4u;     // per-lane byte offset inside a block
+  const unsigned o_lane_b = (unsigned)((4 * h * p.out_ps) + (lane & 31)) * 4u;     // per-lane byte offset inside a block
+  int o_goff[TN];                                                                   // float offset of this wave's 32-column groups
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int gi = ((n0 + wn0) >> 5) + tn;
+    o_goff[tn] = (gi >> 1) * p.out_nA + (gi & 1) * p.out_nB;
+  }
   const float us_a = ldexpf(1.f, -ea), us_b = ldexpf(1.f, -eb);
   // (loaded once: a bias load inside the tile epilogue would wait (vmcnt(0)) for every prefetch in flight)
   float bias_v[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) bias_v[tn] = p.bias ? p.bias[n0 + wn0 + tn * 32 + acc_col(lane)] : 0.f;
-  const int wn = p.W * p.N;
+  const int wn = p.out_rs;
 
   stage_load();
   load_b(std::integral_constant<int, 0>{}, 0, 0);
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     const int beta = tile * NB + wblk;
     const bool live = beta < p.nblk;
     // uniform (scalar) pointer to the block's first pixel; per store: scalar row/pixel offset + one per-lane byte offset
-    const char* ob = reinterpret_cast<const char*>(p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.N);
+    const char* ob = reinterpret_cast<const char*>(p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.out_ps);
     float lsum = 0.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const size_t so = ((size_t)(tm * 4 + (r >> 2)) * wn + (size_t)(r & 3) * p.N + tn * 32) * sizeof(float);   // scalar
+            const size_t so = ((size_t)(tm * 4 + (r >> 2)) * wn + (size_t)(r & 3) * p.out_ps + o_goff[tn]) * sizeof(float);   // scalar
             *reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b) = acc[tm][tn][r];
           }
     }
@@ -464,6 +470,37 @@ __global__ void split_weights_frag_kernel(const float* __restrict__ in, u32x4* _
   out[o + 64] = pl[1];
 }
 
+// 5x5 stride-2 HWIO kernel [5][5][Ci][Co] -> the 3x3 kernel of the same convolution over the space-to-depth view of x:
+// out[u][v][(qy, qx, ci)][co] = w[2u + qy - 1][2v + qx - 1][ci][co], zero where that tap does not exist (11 of the 36 (u, qy) x (v, qx)
+// combinations).  SAME padding (1, 2) of the stride-2 convolution on an even grid = padding (1, 1) of the 3x3 one.
+__global__ void s2d_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Ci, int Co) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = 9LL * 4 * Ci * Co;
+  if (idx >= n) return;
+  const int co = (int)(idx % Co);
+  long long r = idx / Co;
+  const int ci = (int)(r % Ci); r /= Ci;
+  const int q = (int)(r % 4); r /= 4;
+  const int v = (int)(r % 3), u = (int)(r / 3);
+  const int kh = 2 * u + (q >> 1) - 1, kw = 2 * v + (q & 1) - 1;
+  out[idx] = (kh >= 0 && kh < 5 && kw >= 0 && kw < 5) ? w[(((size_t)kh * 5 + kw) * Ci + ci) * Co + co] : 0.f;
+}
+extern "C" int sgg_conv_s2d_weights(const float* w5, float* w3, int Cin, int Cout, void* stream) {
+  SGG_CHECK_ARG(w5 && w3 && Cin > 0 && Cout > 0, "sgg_conv_s2d_weights: bad argument");
+  const long long n = 9LL * 4 * Cin * Cout;
+  hipLaunchKernelGGL(s2d_weights_kernel, dim3((unsigned)sgg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w5, w3, Cin, Cout);
+  SGG_LAUNCH_CHECK("sgg_conv_s2d_weights");
+  return SGG_OK;
+}
+
+// 1 if a 5x5 stride-2 convolution runs as a 3x3 convolution over the space-to-depth view (weights: sgg_conv_s2d_weights, then
+// sgg_conv_split_weights_frag with 9 taps; w_split_layout 3).  Forward: Cin = 32 (a chunk = one pixel parity), any Cout the 3x3
+// kernel takes; dgrad (arguments swapped like sgg_conv_wsplit_layout's): contraction over Cout, 4*Cin = 128 virtual outputs.
+int sgg_s2d_applicable(int KH, int KW, int stride, int Hi, int Wi, int Cin, int Cout, int precision) {
+  return KH == 5 && KW == 5 && stride == 2 && Hi > 0 && Wi > 0 && Hi % 16 == 0 && Wi % 16 == 0 && Cin == 32 && Cout == 32 &&
+         (precision == 2 || precision == 3);
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------
 int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, int precision) {
   return KH == 3 && KW == 3 && stride == 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (C == 32 || C % 64 == 0) && N % 32 == 0 &&
@@ -504,9 +541,12 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
 // halo-resident 3x3 stride-1 kernel).  H, W: the (identical) input and output grid of a stride-1 convolution.
 // 2 = MFMA fragment order with 25 taps for the band-resident 5x5 stride-2 kernel (conv_s2.hip); H, W: the full-resolution grid
 // (forward input / dgrad output); for the dgrad direction pass (Cin, Cout) swapped, as for layout 1.
+// 3 = 5x5 stride 2 over 32 -> 32 channels as a 3x3 convolution over the space-to-depth view: the 9-tap kernel of
+// sgg_conv_s2d_weights ([3][3][128][32]) in fragment order (forward: its HWOI transpose with N = 32, C = 128; dgrad: N = 128, C = 32).
 extern "C" int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision) {
   if (sgg_halo_applicable(KH, KW, stride, H, W, Cin, Cout, precision)) return 1;
   if (sgg_s2_applicable(KH, KW, stride, 1, H, W, Cin, Cout, precision)) return 2;
+  if (sgg_s2d_applicable(KH, KW, stride, H, W, Cin, Cout, precision)) return 3;
   return 0;
 }
 

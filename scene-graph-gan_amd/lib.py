@@ -31,6 +31,7 @@ SIGNATURES = {
     "sgg_conv_split_weights": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
     "sgg_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "sgg_conv_wsplit_layout": (_i, [_i] * 8),
+    "sgg_conv_s2d_weights": (_i, [_vp, _vp, _i, _i, _vp]),
     "sgg_conv_split_weights_frag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
@@ -239,13 +240,21 @@ class HipKernels:
         """w fp32 [kh, kw, N, C] -> out int16 [P, n] sixteen-bit planes (layout 0) or MFMA B fragments (layout 1)."""
         self._dev(w, out, amax)
         amax = self._amax_or_compute(w, amax, 2)
-        if layout in (1, 2):
+        if layout in (1, 2, 3):
             kh, kw, n, c = w.shape
             self._check(self.lib.sgg_conv_split_weights_frag(_p(w), _p(out), kh * kw, n, c, self.conv_precision, _p(amax),
                                                              self._stream()), "sgg_conv_split_weights_frag")
             return
         self._check(self.lib.sgg_conv_split_weights(_p(w), _p(out), w.numel(), self.conv_precision, _p(amax), self._stream()),
                     "sgg_conv_split_weights")
+
+    def s2d_weights(self, w5, w3):
+        """HWIO [5,5,Ci,Co] -> the 9-tap kernel [3,3,4*Ci,Co] of the same stride-2 convolution over the space-to-depth view of x
+        (w_split_layout 3; include/sgg_hip.h)."""
+        self._dev(w5, w3)
+        kh, kw, ci, co = w5.shape
+        assert (kh, kw) == (5, 5) and tuple(w3.shape) == (3, 3, 4 * ci, co) and w5.is_contiguous() and w3.is_contiguous()
+        self._check(self.lib.sgg_conv_s2d_weights(_p(w5), _p(w3), ci, co, self._stream()), "sgg_conv_s2d_weights")
 
     def conv_tile_stats_count(self, y_shape, cin, k=0, stride=0, layout=0):
         """(count, mean, M2) triples per sample the forward conv emits for this output shape in the current mode (0: none)."""
@@ -275,6 +284,7 @@ class HipKernels:
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
+                                                             self.halo_symbol(d[6], 4 * d[3]) if w_split_layout == 3 else
                                                              self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
@@ -289,7 +299,8 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False) if w_split_layout == 2 else
+        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
+                                                                          self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False) if w_split_layout == 2 else
                                                                           self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),

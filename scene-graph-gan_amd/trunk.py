@@ -94,6 +94,10 @@ class Trunk:
             if cin != 3 and getattr(K, "conv_precision", 0) and hasattr(K, "split_weights"):
                 lay["ws_fwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
                 lay["ws_bwd"] = torch.empty((3, lay["w"].numel()), device=dev, dtype=torch.int16)
+            if 3 in (lay["ws_layout"], lay["ws_layout_bwd"]):
+                # conv1_3 as a 3x3 convolution over the space-to-depth view of its input: the 9-tap kernel and its HWOI transpose
+                lay["w3"] = torch.empty((3, 3, 4 * cin, cout), device=dev, dtype=dt)
+                lay["w3_fwd"] = torch.empty((3, 3, cout, 4 * cin), device=dev, dtype=dt)
             lay["tstats"] = None
             if has_ln and hasattr(K, "conv_tile_stats_count") and region is None:
                 nts = K.conv_tile_stats_count((B, ho, wo, cout), cin, k, s, lay["ws_layout"])
@@ -161,8 +165,14 @@ class Trunk:
                     self.K.absmax(lay["w"], self._am(2, j))
                 if lay["ws_fwd"] is not None and self.K.conv_precision:
                     self._query_layouts(lay)
-                    self.K.split_weights(lay["w_fwd"], lay["ws_fwd"], self._am(2, j), lay["ws_layout"])
-                    self.K.split_weights(lay["w"], lay["ws_bwd"], self._am(2, j), lay["ws_layout_bwd"])
+                    if 3 in (lay["ws_layout"], lay["ws_layout_bwd"]):
+                        if "w3" not in lay:
+                            lay["w3"] = torch.empty((3, 3, 4 * lay["cin"], lay["cout"]), device=lay["w"].device, dtype=lay["w"].dtype)
+                            lay["w3_fwd"] = torch.empty((3, 3, lay["cout"], 4 * lay["cin"]), device=lay["w"].device, dtype=lay["w"].dtype)
+                        self.K.s2d_weights(lay["w"], lay["w3"])
+                        self.K.hwio_to_hwoi(lay["w3"], lay["w3_fwd"])
+                    self.K.split_weights(lay["w3_fwd"] if lay["ws_layout"] == 3 else lay["w_fwd"], lay["ws_fwd"], self._am(2, j), lay["ws_layout"])
+                    self.K.split_weights(lay["w3"] if lay["ws_layout_bwd"] == 3 else lay["w"], lay["ws_bwd"], self._am(2, j), lay["ws_layout_bwd"])
                     lay["ws_mode"] = self.K.conv_precision
         self._plan_ln_fusion()
 

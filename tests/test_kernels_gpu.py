@@ -606,6 +606,78 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
         hip.conv_precision = old
 
 
+S2D_CASES = [(2, 16, 16), (3, 48, 32), (1, 64, 112), (5, 32, 16)]      # B, H, W (32 -> 32 channels, H % 16 == W % 16 == 0)
+
+
+@pytest.mark.parametrize("mode", [2, 3], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("case", S2D_CASES)
+def test_conv_s2d_fwd_dgrad(hip, ref, case, mode):
+    """conv1_3 (5x5 stride 2, 32 -> 32 channels) on the halo-resident kernel as a 3x3 convolution over the space-to-depth view of
+    its input (w_split_layout 3): forward (+ LayerNorm partials) and dgrad vs the fp64 reference and vs the gather kernel; the 9-tap
+    kernel of sgg_conv_s2d_weights vs its definition."""
+    from tests import conv_ref64 as R64
+    B, H, W = case
+    Ci = Co = 32
+    old = hip.conv_precision
+    hip.conv_precision = mode
+    try:
+        tol = {2: 2e-5, 3: 1e-4}[mode]
+        assert hip.conv_wsplit_layout(5, 2, H, W, Ci, Co) == 3
+        assert hip.conv_wsplit_layout(5, 2, H + 8, W, Ci, Co) == 0 and hip.conv_wsplit_layout(5, 2, H, W, Ci, 64) == 0
+        x, w, b = rnd((B, H, W, Ci), 11), rnd((5, 5, Ci, Co), 12, 1.0 / math.sqrt(25 * Ci)), rnd((Co,), 13, 0.1)
+        Ho, Wo = H // 2, W // 2
+        dy = rnd((B, Ho, Wo, Co), 14)
+        xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+        w3 = torch.full((3, 3, 4 * Ci, Co), float("nan"), device="cuda")
+        hip.s2d_weights(wd, w3)
+        w3_ref = torch.zeros((3, 3, 2, 2, Ci, Co))
+        for u in range(3):
+            for v in range(3):
+                for qy in range(2):
+                    for qx in range(2):
+                        kh, kw = 2 * u + qy - 1, 2 * v + qx - 1
+                        if 0 <= kh < 5 and 0 <= kw < 5:
+                            w3_ref[u, v, qy, qx] = w[kh, kw]
+        assert torch.equal(w3.cpu(), w3_ref.reshape(3, 3, 4 * Ci, Co))
+        w3f = torch.empty((3, 3, Co, 4 * Ci), device="cuda")
+        hip.hwio_to_hwoi(w3, w3f)
+        wf = torch.empty((5, 5, Co, Ci), device="cuda")
+        hip.hwio_to_hwoi(wd, wf)
+        ws_f = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+        ws_b = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+        hip.split_weights(w3f, ws_f, layout=3)
+        hip.split_weights(w3, ws_b, layout=3)
+        y_ref = R64.conv_fwd64(x.double(), w.double(), b.double(), 2)
+        y = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
+        hip.conv_fwd(xd, wd, wf, bd, y, 2, ws_f, w_split_layout=3)
+        close(y, y_ref, rtol=tol, what="s2d conv_fwd %s" % (case,))
+        y_g = torch.empty_like(y)
+        hip.conv_fwd(xd, wd, wf, bd, y_g, 2)
+        close(y, y_g.cpu(), rtol=5e-6, what="s2d vs gather (forward)")
+        dx_ref = R64.conv_dgrad64(dy.double(), w.double(), (H, W), 2)
+        dx = torch.full((B, H, W, Ci), float("nan"), device="cuda")
+        hip.conv_dgrad(dyd, wd, dx, 2, ws_b, w_split_layout=3)
+        close(dx, dx_ref, rtol=tol, what="s2d conv_dgrad %s" % (case,))
+        dx_g = torch.empty_like(dx)
+        hip.conv_dgrad(dyd, wd, dx_g, 2)
+        close(dx, dx_g.cpu(), rtol=5e-6, what="s2d vs gather (dgrad)")
+        nts = hip.conv_tile_stats_count((B, Ho, Wo, Co), Ci, 5, 2, 3)
+        assert nts == Ho * Wo // 64
+        ts = torch.full((B, nts, 4), float("nan"), device="cuda")
+        y2 = torch.empty_like(y)
+        hip.conv_fwd(xd, wd, wf, bd, y2, 2, ws_f, tile_stats=ts, w_split_layout=3)
+        assert torch.equal(y2, y)
+        gamma, beta = dev(1.0 + rnd((Co,), 15, 0.2)), dev(rnd((Co,), 16, 0.2))
+        a1, a2 = torch.empty_like(y), torch.empty_like(y)
+        st1, st2 = torch.empty((B, 2), device="cuda"), torch.empty((B, 2), device="cuda")
+        hip.ln_elu_fwd(y, gamma, beta, a1, st1, tile_stats=ts)
+        hip.ln_elu_fwd(y, gamma, beta, a2, st2)
+        close(st1, st2.cpu(), rtol=1e-6, what="stats from the s2d epilogue vs statistics pass")
+        close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+    finally:
+        hip.conv_precision = old
+
+
 LNP_CASES = [(2, 16, 24, 32, 32), (3, 8, 16, 64, 64), (2, 24, 16, 64, 128), (3, 8, 8, 128, 128), (1, 16, 16, 128, 256), (2, 8, 8, 256, 256),
              (2, 16, 16, 32, 64), (1, 8, 8, 512, 512)]
 
