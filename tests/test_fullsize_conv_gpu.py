@@ -81,6 +81,13 @@ def run_modes(hip, x, w, b, dy, s, what, do=("fwd", "dgrad", "wgrad")):
                         continue
                     lay = hip.conv_wsplit_layout(k, s, H, W, ci, co)
                     ws = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+                    if lay == 3:     # conv1_3 over the space-to-depth view: the 9-tap kernel (its HWOI transpose for the forward)
+                        w3 = torch.empty((3, 3, 4 * w.shape[2], w.shape[3]), device="cuda")
+                        hip.s2d_weights(wd, w3)
+                        wsrc = w3
+                        if op == "fwd":
+                            wsrc = torch.empty((3, 3, w.shape[3], 4 * w.shape[2]), device="cuda")
+                            hip.hwio_to_hwoi(w3, wsrc)
                     hip.split_weights(wsrc, ws, layout=lay)
                     o = torch.full(tuple(refs[op].shape), float("nan"), device="cuda")
                     if op == "fwd":
