@@ -37,6 +37,9 @@ extern "C" int sgg_halo_prof_read(unsigned long long* out, int reset) {
 #define PROF(...)
 #endif
 
+#ifndef SGG_HALO_DB_MAX
+#define SGG_HALO_DB_MAX 65536   // two patch buffers when they fit in this many bytes of LDS (a gfx950 workgroup may use up to 160 KB; measured: see DESIGN.md)
+#endif
 #define HALO_PITCH 12
 #define HALO_BLKB (10 * HALO_PITCH * 64)   // bytes of one plane of one block's patch
 
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   constexpr int PLANEB = NB * HALO_BLKB;
   constexpr int ITEMS = NB * 400;                       // (block, patch pixel, 8-channel group)
   constexpr int NPASS = (ITEMS + 255) / 256;
-  constexpr bool DB = (2 * P * PLANEB <= 65536);        // two patch buffers: one barrier per chunk instead of two
+  constexpr bool DB = (2 * P * PLANEB <= SGG_HALO_DB_MAX);        // two patch buffers: one barrier per chunk instead of two
   __shared__ __attribute__((aligned(16))) unsigned char lds[(DB ? 2 : 1) * P * PLANEB];
   __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 1024 : 4];      // gamma[0..511], beta at +512 (C <= 512: host check)
 
