@@ -42,7 +42,11 @@ DTYPE_NAME = {0: "f32 (native f32 MFMA)",
               2: "f32 (conv operands scaled per tensor and split into 2 fp16 pieces, round-to-nearest = 23 significant bits, "
                  "3 fp16 MFMAs per product, f32 accumulate; native-f32 figure and parity in the same line)",
               6: "f32 (conv operands split into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate)",
-              3: "f32 storage, conv operands split into 2 bf16 pieces (3 bf16 MFMAs per product, f32 accumulate)"}
+              3: "f32 storage, conv operands split into 2 bf16 pieces (3 bf16 MFMAs per product, f32 accumulate)",
+              1: "f32 storage, conv operands scaled per tensor and ROUNDED TO ONE fp16 PIECE (11 significant bits, one fp16 MFMA per "
+                 "product, f32 accumulate): mixed-precision mode, NOT the reference's arithmetic (SURVEY.md 8 row f4)",
+              4: "f32 storage, conv operands rounded to ONE bf16 piece (8 significant bits, one bf16 MFMA per product, f32 accumulate): "
+                 "mixed-precision mode, NOT the reference's arithmetic (SURVEY.md 8 row f4)"}
 # BASELINE.json configs[i] that fit one GPU: rows per GPU, image side, vocabulary
 CONFIGS = {1: (64, 224, 1000), 3: (64, 224, 70000), 4: (32, 448, 1000)}
 CONFIG_NOTE = {1: "1xMI355X, batch 64, 224x224, vocab 1000", 3: "Visual-Genome-scale vocab 70k", 4: "large image, batch 32, 448x448"}
@@ -113,15 +117,15 @@ def conv_roofline(per, precision, dt):
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(dom)
-    nprod = {0: 1, 2: 3, 3: 3, 6: 6}[precision]
+    nprod = {0: 1, 1: 1, 4: 1, 2: 3, 3: 3, 6: 6}[precision]
     peak = MFMA_BF16_PEAK_TFLOPS / nprod if precision else MFMA_F32_PEAK_TFLOPS
     note = ("dense %s MFMA peak %.0f TFLOP/s / %d MFMA products per algorithmic f32 product"
-            % ("f16" if precision == 2 else "bf16", MFMA_BF16_PEAK_TFLOPS, nprod) if precision else "f32 matrix peak")
+            % ("f16" if precision in (1, 2) else "bf16", MFMA_BF16_PEAK_TFLOPS, nprod) if precision else "f32 matrix peak")
     r = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": peak, "peak_note": note, "unit": "TFLOP/s",
          "frac": fl / sec / 1e12 / peak, "traffic": traffic, "mfma_tflops_issued": nprod * fl / sec / 1e12,
          "vs_native_f32_mfma_peak": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "launches": n, "avg_launch_ms": 1e3 * sec / n,
          "flop_per_launch": fl / n, "share_of_step_time": sec / dt}
-    if precision in (2, 3):
+    if precision in (1, 2, 3, 4):
         # a register-only loop of v_mfma_f32_32x32x16_f16 on random operands sustains 1.56-1.71 PFLOP/s: the chip clocks down
         # under matrix load (2.46 PFLOP/s only with all-zero operands) -> / 3 products
         r["sustained_mfma_peak_measured"] = SUSTAINED_F16_MFMA_TFLOPS / nprod
@@ -214,9 +218,10 @@ def main():
     ap.add_argument("--overlap-streams", action="store_true",
                     help="time the two-stream schedule itself (D's encoder beside G's forward, filter gradients beside dgrad + LayerNorm "
                          "backward: +4 %%; per-kernel event durations are then no roofline evidence)")
-    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 2, 3, 6],
+    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 1, 2, 3, 4, 6],
                     help="conv contraction: 2 = scaled fp16 pieces, 3 products (default), 6 = bf16 pieces, 6 products, "
-                         "0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance)")
+                         "0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance); 1 / 4 = ONE fp16 / bf16 piece, one product "
+                         "(mixed precision: not the reference's arithmetic, not a headline)")
     args = ap.parse_args()
 
     import sgg_amd  # noqa: F401

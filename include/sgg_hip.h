@@ -35,8 +35,12 @@ int sgg_hwio_to_hwoi(const float* w_hwio, float* w_hwoi, int taps, int cin, int 
  *            2 = f32 operands scaled by a per-tensor power of two (from amax_* = device words holding max|tensor|, see
  *                sgg_absmax / the amax_out of the LayerNorm kernels) and split into two fp16 pieces, 3 fp16 MFMAs, f32
  *                accumulate: 22 significant bits per operand, error vs fp64 equal to native f32;
- *            3 / 6 = split into 2 / 3 bf16 pieces, 3 / 6 bf16 MFMAs (6: f32-equivalent, 3: 2^-17 cross terms dropped).
- * amax pointers are only read for precision 2 (may be NULL otherwise). */
+ *            3 / 6 = split into 2 / 3 bf16 pieces, 3 / 6 bf16 MFMAs (6: f32-equivalent, 3: 2^-17 cross terms dropped);
+ *            1 / 4 = MIXED PRECISION (not the reference's arithmetic): operands rounded to ONE fp16 (scaled
+ *                like precision 2) / ONE bf16 piece, one MFMA per product, f32 accumulate - error vs fp64 2e-3 / 1.5e-2 of the
+ *                output's maximum.  Served by the resident kernels (w_split_layout 1 / 2 / 3, the halo-resident wgrad); other
+ *                shapes run these codes in the two-piece arithmetic (2 / 3).  The pre-split weights are the ones of precision 2 / 3.
+ * amax pointers are only read for precision 1 / 2 (may be NULL otherwise). */
 /* w_split (optional, may be NULL): the same weights pre-split by sgg_split_bf16 into precision/2 bf16 planes [P][n];
  * saves the per-workgroup split of the weight operand in the split-bf16 modes. */
 int sgg_conv_split_weights(const float* in, void* out, long long n, int precision, const float* amax, void* stream);

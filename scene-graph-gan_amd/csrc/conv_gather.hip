@@ -714,6 +714,7 @@ static void launch_gather_bf16s(const GatherParams& p, hipStream_t st) {
 
 // precision: 0 = native f32 MFMA; 2 = scaled f16 pieces, 3 products; 3 / 6 = bf16 pieces, 3 / 6 products
 static int dispatch_gather(const GatherParams& p, hipStream_t st, int precision) {
+  precision = sgg_prec_general(precision);      // (no single-piece variant of the gather kernel: modes 1 / 4 run as 2 / 3 here)
   const bool small_ = (size_t)p.B * p.Hs * p.Ws * p.C * sizeof(float) < 0x80000000ull && p.w_bytes < 0x80000000u;
   if (precision != 0 && small_) {
 #define SGG_GB(BM, BN, WGM, WGN)                                                        \
@@ -761,6 +762,7 @@ __global__ void split_weights_kernel(const float* __restrict__ in, unsigned* __r
 
 // `amax` (device word with max|w|, see sgg_absmax) is required for precision 2 and ignored otherwise
 extern "C" int sgg_conv_split_weights(const float* in, void* out, long long n, int precision, const float* amax, void* stream) {
+  precision = sgg_prec_general(precision);
   SGG_CHECK_ARG(in && out && n > 0 && n % 8 == 0 && (precision == 2 || precision == 3 || precision == 6) && (precision != 2 || amax),
                 "sgg_conv_split_weights: bad argument");
   const long long n8 = n / 8;
@@ -813,8 +815,9 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
   SGG_CHECK_ARG(!ln_stats || (w_split_layout == 1 && ln_gamma && ln_beta && Cin <= 512),
                 "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1 (halo-resident kernel), gamma, beta and Cin <= 512");
-  SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 2, 3 or 6");
-  SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 2 needs the amax words");
+  SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 1, 2, 3, 4 or 6");
+  SGG_CHECK_ARG(!sgg_prec_half(precision) || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 1 / 2 need the amax words");
+  SGG_CHECK_ARG(!ln_stats || !sgg_prec_one(precision), "sgg_conv2d_nhwc_fwd: the LN prologue exists in the two-piece modes (2, 3) only");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_fwd: bad dims");
   SGG_CHECK_ARG(Ho == (Hi + stride - 1) / stride && Wo == (Wi + stride - 1) / stride,
                 "sgg_conv2d_nhwc_fwd: Ho/Wo must be ceil(in/stride) (SAME padding)");
@@ -906,8 +909,8 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
                                      int w_split_layout, const float* amax_dy, const float* amax_w, void* stream) {
   SGG_CHECK_ARG(dy && w && dx, "sgg_conv2d_nhwc_dgrad: null pointer");
-  SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6, "sgg_conv2d_nhwc_dgrad: precision must be 0, 2, 3 or 6");
-  SGG_CHECK_ARG(precision != 2 || (amax_dy && amax_w), "sgg_conv2d_nhwc_dgrad: precision 2 needs the amax words");
+  SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6, "sgg_conv2d_nhwc_dgrad: precision must be 0, 1, 2, 3, 4 or 6");
+  SGG_CHECK_ARG(!sgg_prec_half(precision) || (amax_dy && amax_w), "sgg_conv2d_nhwc_dgrad: precision 1 / 2 need the amax words");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_dgrad: bad dims");
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_dgrad: Cin and Cout must be multiples of 32");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),

@@ -49,9 +49,10 @@ __device__ __forceinline__ int halo_sw(int ry, int rx) { return ((rx >> 2) & 1) 
 // flips once per chunk (nine taps), so chunks are unrolled in pairs - a run-time parity branch between two chunk bodies
 // costs ~110 spilled VGPRs at the merge.
 // LNP: LN prologue - src is the producing layer's pre-LayerNorm output, normalised + ELU'd while the patch is staged.
-template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH, bool LNP>
+// ONE: single-piece mode (precision 1 / 4): one 16-bit plane, one MFMA per product.
+template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH, bool LNP, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
-  constexpr int P = 2;
+  constexpr int P = ONE ? 1 : 2;
   constexpr int WN = BN / WGN, TM = 2, TN = WN / 32;
   static_assert(WGM * WGN == 4 && NB * 64 / WGM == 64 && WN % 32 == 0 && TN >= 1, "a wave owns one 8x8 block x WN columns");
   constexpr int PLANEB = NB * HALO_BLKB;
@@ -266,8 +267,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         f32x16 d = acc[tm][tn];
-        d = mfma16<HALF>(a[par][tm][ks][1], rb[par][tn][ks][0], d);
-        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][1], d);
+        if constexpr (P == 2) {
+          d = mfma16<HALF>(a[par][tm][ks][1], rb[par][tn][ks][0], d);
+          d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][1], d);
+        }
         d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][0], d);
         acc[tm][tn] = d;
       }
@@ -501,20 +504,20 @@ extern "C" int sgg_conv_s2d_weights(const float* w5, float* w3, int Cin, int Cou
 // kernel takes; dgrad (arguments swapped like sgg_conv_wsplit_layout's): contraction over Cout, 4*Cin = 128 virtual outputs.
 int sgg_s2d_applicable(int KH, int KW, int stride, int Hi, int Wi, int Cin, int Cout, int precision) {
   return KH == 5 && KW == 5 && stride == 2 && Hi > 0 && Wi > 0 && Hi % 16 == 0 && Wi % 16 == 0 && Cin == 32 && Cout == 32 &&
-         (precision == 2 || precision == 3);
+         sgg_prec_resident(precision);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
 int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, int precision) {
   return KH == 3 && KW == 3 && stride == 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (C == 32 || C % 64 == 0) && N % 32 == 0 &&
-         (precision == 2 || precision == 3);
+         sgg_prec_resident(precision);
 }
 
 int sgg_halo_stats_cols(int N) { return (N % 64 == 0) ? 64 : 32; }
 
 void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
   HaloParams p = p_;
-  const bool half = precision == 2;
+  const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);   // (the LN prologue exists in the two-piece modes only: callers check)
 #define SGG_HALO(NB, BN, WGM, WGN, PF)                                                                       \
   do {                                                                                                       \
     const int mtiles = sgg_cdiv(p.nblk, NB), ntn = p.N / BN;                                                 \
@@ -523,7 +526,12 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
     gx = sgg_cdiv(gx, ntn) * ntn;                                                                            \
     p.gx = gx;                                                                                               \
     const dim3 grid((unsigned)(8 * gx));                                                                     \
-    if (p.ln_stats) {                                                                                                                  \
+    if (one) {                                                                                                                          \
+      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false, true>), grid, dim3(256), 0, st, p);   \
+      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false, true>), grid, dim3(256), 0, st, p);      \
+      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false, true>), grid, dim3(256), 0, st, p); \
+      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false, true>), grid, dim3(256), 0, st, p);               \
+    } else if (p.ln_stats) {                                                                                                            \
       if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, true>), grid, dim3(256), 0, st, p);   \
       else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, true>), grid, dim3(256), 0, st, p);      \
       else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, true>), grid, dim3(256), 0, st, p); \
@@ -557,6 +565,8 @@ extern "C" int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, 
 // out: taps*N*C*4 bytes.  precision 2 needs `amax` (device word with max|w|).
 extern "C" int sgg_conv_split_weights_frag(const float* in, void* out, int taps, int N, int C, int precision, const float* amax,
                                            void* stream) {
+  // (the single-piece modes 1 / 4 read plane 0 of the same fragments: the first piece of the split IS the rounded operand)
+  precision = sgg_prec_general(precision);
   SGG_CHECK_ARG(in && out && taps > 0 && N > 0 && C > 0 && N % 32 == 0 && C % 32 == 0 && (precision == 2 || precision == 3) &&
                     (precision != 2 || amax),
                 "sgg_conv_split_weights_frag: bad argument");

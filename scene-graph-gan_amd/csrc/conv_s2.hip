@@ -62,9 +62,10 @@ constexpr int cls_ntaps(int cls) { return (cls_qy(cls) ? 3 : 2) * (cls_qx(cls) ?
 
 // MT = MFMA row tiles per band: 7 (224 positions), or 4 (128 positions) where 224-position bands would give fewer
 // (band, n-tile) work items than the chip has CUs (`downsampled` at batch 64: 56 bands x 4 n-tiles).
-template <bool DGRAD, bool HALF, int MT>
+// ONE: single-piece mode (precision 1 / 4): one 16-bit plane, one MFMA per product.
+template <bool DGRAD, bool HALF, int MT, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
-  constexpr int P = 2;
+  constexpr int P = ONE ? 1 : 2;
   constexpr int BAND = 32 * MT;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * S2_PLB];
   __shared__ __attribute__((aligned(16))) int rowtab[2][BAND];      // byte offset of each band row in `out` (-1: past the end)
@@ -202,13 +203,15 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     if constexpr (dxx == 2) off = edge_r[t] ? S2_ZSLOT * 32 : off;      // column Wo
     const unsigned char* a_ptr = lds + cur * (P * S2_PLB) + off;
     ra[ring][0] = *reinterpret_cast<const u32x4*>(a_ptr);
-    ra[ring][1] = *reinterpret_cast<const u32x4*>(a_ptr + S2_PLB);
+    if constexpr (P == 2) ra[ring][1] = *reinterpret_cast<const u32x4*>(a_ptr + S2_PLB);
   };
   auto mma_tile = [&](auto ring_c, auto t_c, auto par_c) __attribute__((always_inline)) {
     constexpr int ring = decltype(ring_c)::value, t = decltype(t_c)::value, par = decltype(par_c)::value;
     f32x16 d = acc[t];
-    d = mfma16<HALF>(ra[ring][1], rb[par][0], d);
-    d = mfma16<HALF>(ra[ring][0], rb[par][1], d);
+    if constexpr (P == 2) {
+      d = mfma16<HALF>(ra[ring][1], rb[par][0], d);
+      d = mfma16<HALF>(ra[ring][0], rb[par][1], d);
+    }
     d = mfma16<HALF>(ra[ring][0], rb[par][0], d);
     acc[t] = d;
   };
@@ -411,7 +414,7 @@ static int s2_max_rows(int Ho, int Wo, int band = S2_BAND) {
 int sgg_s2_applicable(int KH, int KW, int stride, int B, int Hi, int Wi, int C, int N, int precision) {
   (void)B;
   if (!(KH == 5 && KW == 5 && stride == 2 && Hi > 0 && Wi > 0 && Hi % 2 == 0 && Wi % 2 == 0 && C % 32 == 0 && N % S2_BN == 0 &&
-        (precision == 2 || precision == 3)))
+        sgg_prec_resident(precision)))
     return 0;
   const int Ho = Hi / 2, Wo = Wi / 2;
   return s2_max_rows(Ho, Wo) * Wo <= S2_ZSLOT;      // the patch (pitch Wo, no halo columns) must leave the zero slot free
@@ -430,10 +433,18 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
   gx = sgg_cdiv(gx, ntn) * ntn;
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx));
-  const bool half = precision == 2;
+  const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);
 #define SGG_S2(MT)                                                                                      \
   do {                                                                                                  \
-    if (dgrad) {                                                                                        \
+    if (one) {                                                                                          \
+      if (dgrad) {                                                                                      \
+        if (half) hipLaunchKernelGGL((conv_s2_kernel<true, true, MT, true>), grid, dim3(256), 0, st, p);  \
+        else hipLaunchKernelGGL((conv_s2_kernel<true, false, MT, true>), grid, dim3(256), 0, st, p);      \
+      } else {                                                                                          \
+        if (half) hipLaunchKernelGGL((conv_s2_kernel<false, true, MT, true>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((conv_s2_kernel<false, false, MT, true>), grid, dim3(256), 0, st, p);     \
+      }                                                                                                 \
+    } else if (dgrad) {                                                                                 \
       if (half) hipLaunchKernelGGL((conv_s2_kernel<true, true, MT>), grid, dim3(256), 0, st, p);        \
       else hipLaunchKernelGGL((conv_s2_kernel<true, false, MT>), grid, dim3(256), 0, st, p);            \
     } else {                                                                                            \

@@ -611,9 +611,10 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   SGG_CHECK_ARG(x && dy && dw, "sgg_conv2d_nhwc_wgrad: null pointer");
   SGG_CHECK_ARG(!ln_stats || (ln_gamma && ln_beta), "sgg_conv2d_nhwc_wgrad: the LN prologue needs stats, gamma and beta");
   SGG_CHECK_ARG(algo == 0 || algo == 1, "sgg_conv2d_nhwc_wgrad: algo must be 0 (auto) or 1 (per-tap kernels only)");
-  SGG_CHECK_ARG(precision == 0 || precision == 2 || precision == 3 || precision == 6,
-                "sgg_conv2d_nhwc_wgrad: precision must be 0, 2, 3 or 6");
-  SGG_CHECK_ARG(precision != 2 || Cin == 3 || (amax_x && amax_dy), "sgg_conv2d_nhwc_wgrad: precision 2 needs the amax words");
+  SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6,
+                "sgg_conv2d_nhwc_wgrad: precision must be 0, 1, 2, 3, 4 or 6");
+  SGG_CHECK_ARG(!sgg_prec_half(precision) || Cin == 3 || (amax_x && amax_dy), "sgg_conv2d_nhwc_wgrad: precision 1 / 2 need the amax words");
+  SGG_CHECK_ARG(!ln_stats || !sgg_prec_one(precision), "sgg_conv2d_nhwc_wgrad: the LN prologue exists in the two-piece modes (2, 3) only");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_wgrad: bad dims");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
                 "sgg_conv2d_nhwc_wgrad: tensor exceeds 2^31 elements");
@@ -627,7 +628,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
   }
   const long long nout = (long long)KH * KW * Cin * Cout;
   WgradHaloPlan hp;
-  if ((precision == 2 || precision == 3) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho * stride && Wi == Wo * stride &&
+  if (sgg_prec_resident(precision) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho * stride && Wi == Wo * stride &&
       algo == 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp) && !(hp.geo == 1 && ln_stats)) {
     // halo-resident kernel: the nine taps of a channel chunk from one LDS-resident patch (conv_wgrad_halo.hip)
     if (!workspace || workspace_bytes < hp.ws_bytes) {
@@ -671,6 +672,7 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
                     (size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull && (size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull,
                 "sgg_conv2d_nhwc_wgrad: tensor too large for the 32-bit offset path");
   dim3 grid(pl.tiles, KH * KW, pl.nsplit);
+  precision = sgg_prec_general(precision);      // (the per-tap kernels have no single-piece variant: modes 1 / 4 run as 2 / 3 here)
 #define SGG_WG(BMC, BNC, WM, WN)                                                                        \
   do {                                                                                                \
     if (precision == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNC, WM, WN, 0, false>), grid, dim3(256), 0, st, p);      \

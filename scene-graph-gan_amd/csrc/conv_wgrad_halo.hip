@@ -59,11 +59,13 @@ struct WgradHaloParams {
 
 // NKH x NKW: taps of the launch (3x3 for the stride-1 kernel; 3x3 / 3x2 / 2x3 / 2x2 for the four parity classes of a 5x5
 // stride-2 kernel, each a stride-1 problem on the sub-sampled x grid).
-template <int CT, int NT, bool HALF, bool PREF, int NKH, int NKW, bool LNP, int GEO = 0>
+// ONE: single-piece mode (precision 1 / 4): one 16-bit plane per operand, one MFMA per product.
+template <int CT, int NT, bool HALF, bool PREF, int NKH, int NKW, bool LNP, int GEO = 0, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParams p) {
   static_assert(GEO == 0 || (CT == 2 && NT == 2 && !LNP), "row bands: 64 x 64 channel chunks only");
+  static_assert(!(ONE && LNP), "the LN prologue exists in the two-piece modes only");
   constexpr int NTAP = NKH * NKW;
-  constexpr int P = 2;
+  constexpr int P = ONE ? 1 : 2;
   constexpr int NBS = (CT == 2) ? 1 : 2;                 // blocks per stage
   constexpr int KSW = GEO ? 7 : ((CT == 1 && NT == 1) ? 2 : 4);      // 16-pixel MFMA steps per wave and block
   constexpr int SPW = 4 / (CT * NT) ;                    // waves that share a channel tile (own slabs)
@@ -330,8 +332,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
             a[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
           }
           f32x16 d = acc[tap];
-          d = mfma16<HALF>(a[1], b[0], d);
-          d = mfma16<HALF>(a[0], b[1], d);
+          if constexpr (P == 2) {
+            d = mfma16<HALF>(a[1], b[0], d);
+            d = mfma16<HALF>(a[0], b[1], d);
+          }
           d = mfma16<HALF>(a[0], b[0], d);
           acc[tap] = d;
         }
@@ -358,8 +362,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
           a[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
         f32x16 d = acc[tap];
-        d = mfma16<HALF>(a[1], b[0], d);
-        d = mfma16<HALF>(a[0], b[1], d);
+        if constexpr (P == 2) {
+          d = mfma16<HALF>(a[1], b[0], d);
+          d = mfma16<HALF>(a[0], b[1], d);
+        }
         d = mfma16<HALF>(a[0], b[0], d);
         acc[tap] = d;
       }
@@ -461,16 +467,22 @@ int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, 
 }
 
 template <int NKH, int NKW>
-static void wgrad_halo_launch_class(const WgradHaloParams& p, const WgradHaloPlan& pl, bool half, hipStream_t st) {
+static void wgrad_halo_launch_class(const WgradHaloParams& p, const WgradHaloPlan& pl, bool half, bool one, hipStream_t st) {
   const dim3 grid(pl.nsplit, pl.pairs);
   if (pl.geo == 1) {   // row bands (64 x 64 channel chunks, no LN prologue: host checks)
-    if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<2, 2, true, true, NKH, NKW, false, 1>), grid, dim3(256), 0, st, p);
+    if (one) {
+      if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<2, 2, true, true, NKH, NKW, false, 1, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<2, 2, false, true, NKH, NKW, false, 1, true>), grid, dim3(256), 0, st, p);
+    } else if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<2, 2, true, true, NKH, NKW, false, 1>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<2, 2, false, true, NKH, NKW, false, 1>), grid, dim3(256), 0, st, p);
     return;
   }
 #define SGG_WH(CT, NT, PF)                                                                                          \
   do {                                                                                                              \
-    if (p.ln_stats) {                                                                                               \
+    if (one) {                                                                                                      \
+      if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF, NKH, NKW, false, 0, true>), grid, dim3(256), 0, st, p);   \
+      else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF, NKH, NKW, false, 0, true>), grid, dim3(256), 0, st, p);       \
+    } else if (p.ln_stats) {                                                                                        \
       if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF, NKH, NKW, true>), grid, dim3(256), 0, st, p);   \
       else hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, false, PF, NKH, NKW, true>), grid, dim3(256), 0, st, p);       \
     } else if (half) hipLaunchKernelGGL((conv_wgrad_halo3_kernel<CT, NT, true, PF, NKH, NKW, false>), grid, dim3(256), 0, st, p);   \
@@ -497,10 +509,10 @@ void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B,
   p.pairs_n = pl.pairs_n; p.stages = pl.stages;
   p.x_bytes = (unsigned)((size_t)B * p.Hx * p.Wx * Cin * sizeof(float));
   p.dy_bytes = (unsigned)((size_t)B * H * W * Cout * sizeof(float));
-  const bool half = precision == 2;
+  const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);
   if (stride == 1) {
     p.cy = p.cx = 0; p.a0y = p.a0x = -1; p.kh0 = p.kw0 = 0; p.kstep = 1; p.KWt = 3; p.taps_total = 9;
-    wgrad_halo_launch_class<3, 3>(p, pl, half, st);
+    wgrad_halo_launch_class<3, 3>(p, pl, half, one, st);
     return;
   }
   p.kstep = 2; p.KWt = 5; p.taps_total = 25;
@@ -512,9 +524,9 @@ void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B,
       p.a0y = (kh0 - pad_t - cy) / 2;           // exact: kh0 - pad_t - cy is even (and <= 0)
       p.a0x = (kw0 - pad_l - cx) / 2;
       const int nkh = (5 - kh0 + 1) / 2, nkw = (5 - kw0 + 1) / 2;
-      if (nkh == 3 && nkw == 3) wgrad_halo_launch_class<3, 3>(p, pl, half, st);
-      else if (nkh == 3) wgrad_halo_launch_class<3, 2>(p, pl, half, st);
-      else if (nkw == 3) wgrad_halo_launch_class<2, 3>(p, pl, half, st);
-      else wgrad_halo_launch_class<2, 2>(p, pl, half, st);
+      if (nkh == 3 && nkw == 3) wgrad_halo_launch_class<3, 3>(p, pl, half, one, st);
+      else if (nkh == 3) wgrad_halo_launch_class<3, 2>(p, pl, half, one, st);
+      else if (nkw == 3) wgrad_halo_launch_class<2, 3>(p, pl, half, one, st);
+      else wgrad_halo_launch_class<2, 2>(p, pl, half, one, st);
     }
 }

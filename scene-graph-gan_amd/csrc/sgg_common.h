@@ -101,6 +101,14 @@ __device__ __forceinline__ void f16_split2(float a, float b, unsigned& hi, unsig
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// precision code of the C ABI -> (HALF, pieces) of the resident split kernels: 2 = fp16 x 2 pieces (3 products), 3 = bf16 x 2,
+// 1 = ONE fp16 piece (one product: mixed-precision arithmetic, tolerance 2e-3), 4 = one bf16 piece (1.5e-2)
+static inline bool sgg_prec_resident(int precision) { return precision >= 1 && precision <= 4; }
+static inline bool sgg_prec_half(int precision) { return precision == 1 || precision == 2; }
+static inline bool sgg_prec_one(int precision) { return precision == 1 || precision == 4; }
+// kernels without a single-piece variant run the two-piece mode of the same number format
+static inline int sgg_prec_general(int precision) { return precision == 1 ? 2 : (precision == 4 ? 3 : precision); }
+
 // XCD-aware bijective block remap (cdna_hip_programming.md T1): consecutive logical ids share an XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;

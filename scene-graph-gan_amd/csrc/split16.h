@@ -31,7 +31,9 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float s
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float a = x[2 * q], b = x[2 * q + 1];
-    if constexpr (HALF) {
+    if constexpr (HALF && P == 1) {     // single-piece mode: the operand rounded to fp16 (11 significant bits)
+      pl[0][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a * scale, b * scale}, fp16x2));
+    } else if constexpr (HALF) {
       a *= scale; b *= scale;
       unsigned hi, lo;
       f16_split2(a, b, hi, lo);

@@ -139,7 +139,7 @@ class HipKernels:
         #                for consumers with 64+ input channels: measured 53.4 vs 52.9 ms per step - still slower;
         #   2          : everywhere the halo-resident kernels allow: 60.2 vs 53.6 ms per step (wgrad +17 %, conv1_2 5x slower).
         self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "0"))
-        assert self.conv_precision in (0, 2, 3, 6)
+        assert self.conv_precision in (0, 1, 2, 3, 4, 6)       # 1 / 4: single-piece (mixed-precision) modes, include/sgg_hip.h
         self._amax_by_stream = {}
 
     def _timed(self, symbol, flops, fn, nbytes=0.0):
@@ -160,7 +160,7 @@ class HipKernels:
             tile = "128,128,2,2" if n_out % 128 == 0 else ("256,64,4,1" if n_out % 64 == 0 else "256,32,4,1")
             return "conv_gather_bf16s_kernel<%s,%d,%s,%s,32>" % (tile, 3 if self.conv_precision == 6 else 2,
                                                                 "true" if presplit else "false",
-                                                                "true" if self.conv_precision == 2 else "false")
+                                                                "true" if self.conv_precision in (1, 2) else "false")
         if n_out % 128 == 0:
             return "conv_gather3_kernel<128,128,2,2,32>"
         return "conv_gather_kernel<256,64,4,1>" if n_out % 64 == 0 else "conv_gather3_kernel<256,32,4,1,32>"
@@ -217,7 +217,7 @@ class HipKernels:
 
     def _amax_or_compute(self, t, amax, slot):
         """precision 2 needs max|t| on the device; callers that track it pass `amax`, otherwise it is computed here."""
-        if self.conv_precision != 2 or amax is not None or t is None:
+        if self.conv_precision not in (1, 2) or amax is not None or t is None:
             return amax
         sid = torch.cuda.current_stream(self.device).cuda_stream     # scratch words per stream, like workspace()
         scratch = self._amax_by_stream.get(sid)
@@ -263,14 +263,16 @@ class HipKernels:
 
     def halo_symbol(self, n_out, n_in, lnp=False):
         tile = "2,128,2,2" if n_out % 128 == 0 else ("4,64,4,1" if n_out % 64 == 0 else "4,32,4,1")
-        return "conv_halo3_kernel<%s,%s,%s,%s,%s>" % (tile, "true" if self.conv_precision == 2 else "false",
-                                                      "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false",
-                                                      "true" if n_in == 32 else "false", "true" if lnp else "false")
+        return "conv_halo3_kernel<%s,%s,%s,%s,%s,%s>" % (tile, "true" if self.conv_precision in (1, 2) else "false",
+                                                         "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false",
+                                                         "true" if n_in == 32 else "false", "true" if lnp else "false",
+                                                         "true" if self.conv_precision in (1, 4) else "false")
 
     def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True):
         """(csrc/conv_s2.hip: sgg_s2_launch picks 128-position bands when 224-position ones give at most 256 work items)"""
         mt = 4 if (not stats and -(-m_positions // 224) * (n_out // 128) <= 256) else 7
-        return "conv_s2_kernel<%s,%s,%d>" % ("true" if dgrad else "false", "true" if self.conv_precision == 2 else "false", mt)
+        return "conv_s2_kernel<%s,%s,%d,%s>" % ("true" if dgrad else "false", "true" if self.conv_precision in (1, 2) else "false", mt,
+                                                "true" if self.conv_precision in (1, 4) else "false")
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0,
                  ln=None):

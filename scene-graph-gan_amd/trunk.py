@@ -131,7 +131,7 @@ class Trunk:
             lay["ws_layout_bwd"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cout"], lay["cin"])
 
     def _f16(self):
-        return getattr(self.K, "conv_precision", 0) == 2
+        return getattr(self.K, "conv_precision", 0) in (1, 2)      # fp16 pieces: per-tensor scaling from the amax words
 
     def _am(self, row, j):
         return self.amax[row, j:j + 1] if self._f16() else None

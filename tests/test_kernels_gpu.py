@@ -63,14 +63,18 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=[0, 2, 6, 3], ids=["f32mfma", "f16x3", "bf16x6", "bf16x3"])
+ONE_PIECE_TOL = {1: 2e-3, 4: 1.5e-2}     # single-piece (mixed-precision) modes: operands rounded to fp16 (2^-11) / bf16 (2^-8)
+
+
+@pytest.fixture(params=[0, 2, 6, 3, 1, 4], ids=["f32mfma", "f16x3", "bf16x6", "bf16x3", "f16x1", "bf16x1"])
 def conv_mode(request, hip):
     """conv precision modes of the C ABI: native f32 MFMA, f32 operands scaled and split into two fp16 pieces (3 products),
     or into bf16 pieces (6 / 3 products).  Tolerance vs the fp64 reference: f32, f16x3 and bf16x6 2e-5 * max|ref|
-    (f32-equivalent), bf16x3 (drops 2^-17 cross terms) 1e-4."""
+    (f32-equivalent), bf16x3 (drops 2^-17 cross terms) 1e-4; the single-piece modes 1 / 4 (one product of operands rounded to
+    fp16 / bf16: mixed-precision arithmetic) 2e-3 / 1.5e-2."""
     old = hip.conv_precision
     hip.conv_precision = request.param
-    yield {0: 2e-5, 2: 2e-5, 6: 2e-5, 3: 1e-4}[request.param]
+    yield {0: 2e-5, 2: 2e-5, 6: 2e-5, 3: 1e-4, **ONE_PIECE_TOL}[request.param]
     hip.conv_precision = old
 
 
@@ -411,7 +415,7 @@ HALO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [2, 3], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", [2, 3, 1, 4], ids=["f16x3", "bf16x3", "f16x1", "bf16x1"])
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
     """Halo-resident 3x3 stride-1 kernel (weights as MFMA fragments) vs the fp64 reference and vs the gather kernel."""
@@ -419,7 +423,7 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
     old = hip.conv_precision
     hip.conv_precision = mode
     try:
-        tol = {2: 2e-5, 3: 1e-4}[mode]
+        tol = {2: 2e-5, 3: 1e-4, **ONE_PIECE_TOL}[mode]
         assert hip.conv_wsplit_layout(3, 1, H, W, Ci, Co) == 1
         assert hip.conv_wsplit_layout(3, 1, H + 1, W, Ci, Co) == 0 and hip.conv_wsplit_layout(5, 2, H, W, Ci, Co) != 1
         x, w, b = rnd((B, H, W, Ci), 11), rnd((3, 3, Ci, Co), 12, 1.0 / math.sqrt(9 * Ci)), rnd((Co,), 13, 0.1)
@@ -450,7 +454,7 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
         # same operands through the gather kernel: identical pieces and products, only the summation order differs
         y_g = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y_g, 1)
-        close(y, y_g.cpu(), rtol=5e-6, what="halo vs gather")
+        close(y, y_g.cpu(), rtol=5e-6 if mode in (2, 3) else 2.0 * tol, what="halo vs gather")
         # LayerNorm partial statistics from the halo epilogue
         nts = hip.conv_tile_stats_count((B, H, W, Co), Ci, 3, 1, 1)
         assert nts == (H * W // 64) * (Co // (64 if Co % 64 == 0 else 32))
@@ -549,7 +553,7 @@ S2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [2, 3], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", [2, 3, 1, 4], ids=["f16x3", "bf16x3", "f16x1", "bf16x1"])
 @pytest.mark.parametrize("case", S2_CASES)
 def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
     """Band-resident 5x5 stride-2 kernel (csrc/conv_s2.hip) vs the fp64 reference and vs the gather kernel."""
@@ -558,7 +562,8 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
     old = hip.conv_precision
     hip.conv_precision = mode
     try:
-        tol = {2: 2e-5, 3: 1e-4}[mode]
+        tol = {2: 2e-5, 3: 1e-4, **ONE_PIECE_TOL}[mode]
+        vs_gather = 5e-6 if mode in (2, 3) else 2.0 * tol     # (the gather kernel runs the single-piece modes as two-piece ones)
         assert hip.conv_wsplit_layout(5, 2, H, H, Ci, Co) == 2
         assert hip.conv_wsplit_layout(5, 2, H + 1, H, Ci, Co) == 0          # odd sizes have different SAME pads: gather kernel
         x, w, b = rnd((B, H, H, Ci), 11), rnd((5, 5, Ci, Co), 12, 1.0 / math.sqrt(25 * Ci)), rnd((Co,), 13, 0.1)
@@ -575,7 +580,7 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
         close(y, y_ref, rtol=tol, what="s2 conv_fwd %s" % (case,))
         y_g = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y_g, 2)
-        close(y, y_g.cpu(), rtol=5e-6, what="s2 vs gather (forward)")
+        close(y, y_g.cpu(), rtol=vs_gather, what="s2 vs gather (forward)")
         if hip.conv_wsplit_layout(5, 2, H, H, Co, Ci) == 2:                  # dgrad direction: output channels = Cin
             dx_ref = R64.conv_dgrad64(dy.double(), w.double(), (H, H), 2)
             ws_b = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
@@ -585,7 +590,7 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
             close(dx, dx_ref, rtol=tol, what="s2 conv_dgrad %s" % (case,))
             dx_g = torch.empty_like(dx)
             hip.conv_dgrad(dyd, wd, dx_g, 2)
-            close(dx, dx_g.cpu(), rtol=5e-6, what="s2 vs gather (dgrad)")
+            close(dx, dx_g.cpu(), rtol=vs_gather, what="s2 vs gather (dgrad)")
         else:
             assert Ci % 128 != 0
         nts = hip.conv_tile_stats_count((B, Ho, Ho, Co), Ci, 5, 2, 2)
@@ -609,7 +614,7 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
 S2D_CASES = [(2, 16, 16), (3, 48, 32), (1, 64, 112), (5, 32, 16)]      # B, H, W (32 -> 32 channels, H % 16 == W % 16 == 0)
 
 
-@pytest.mark.parametrize("mode", [2, 3], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", [2, 3, 1], ids=["f16x3", "bf16x3", "f16x1"])
 @pytest.mark.parametrize("case", S2D_CASES)
 def test_conv_s2d_fwd_dgrad(hip, ref, case, mode):
     """conv1_3 (5x5 stride 2, 32 -> 32 channels) on the halo-resident kernel as a 3x3 convolution over the space-to-depth view of
@@ -621,7 +626,8 @@ def test_conv_s2d_fwd_dgrad(hip, ref, case, mode):
     old = hip.conv_precision
     hip.conv_precision = mode
     try:
-        tol = {2: 2e-5, 3: 1e-4}[mode]
+        tol = {2: 2e-5, 3: 1e-4, **ONE_PIECE_TOL}[mode]
+        vs_gather = 5e-6 if mode in (2, 3) else 2.0 * tol
         assert hip.conv_wsplit_layout(5, 2, H, W, Ci, Co) == 3
         assert hip.conv_wsplit_layout(5, 2, H + 8, W, Ci, Co) == 0 and hip.conv_wsplit_layout(5, 2, H, W, Ci, 64) == 0
         x, w, b = rnd((B, H, W, Ci), 11), rnd((5, 5, Ci, Co), 12, 1.0 / math.sqrt(25 * Ci)), rnd((Co,), 13, 0.1)
@@ -653,14 +659,14 @@ def test_conv_s2d_fwd_dgrad(hip, ref, case, mode):
         close(y, y_ref, rtol=tol, what="s2d conv_fwd %s" % (case,))
         y_g = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y_g, 2)
-        close(y, y_g.cpu(), rtol=5e-6, what="s2d vs gather (forward)")
+        close(y, y_g.cpu(), rtol=vs_gather, what="s2d vs gather (forward)")
         dx_ref = R64.conv_dgrad64(dy.double(), w.double(), (H, W), 2)
         dx = torch.full((B, H, W, Ci), float("nan"), device="cuda")
         hip.conv_dgrad(dyd, wd, dx, 2, ws_b, w_split_layout=3)
         close(dx, dx_ref, rtol=tol, what="s2d conv_dgrad %s" % (case,))
         dx_g = torch.empty_like(dx)
         hip.conv_dgrad(dyd, wd, dx_g, 2)
-        close(dx, dx_g.cpu(), rtol=5e-6, what="s2d vs gather (dgrad)")
+        close(dx, dx_g.cpu(), rtol=vs_gather, what="s2d vs gather (dgrad)")
         nts = hip.conv_tile_stats_count((B, Ho, Wo, Co), Ci, 5, 2, 3)
         assert nts == Ho * Wo // 64
         ts = torch.full((B, nts, 4), float("nan"), device="cuda")

@@ -82,3 +82,38 @@ def test_gd_step_matches_oracle_config1(hip, scale_emb):
     assert margin > 1e-4, "seed gives an argmax margin inside the fp tolerance"
     assert torch.equal(toks, O.argmax_tokens(gaux["fake"]))
 
+
+
+@pytest.mark.parametrize("mode,loss_tol,grad_tol", [(1, 3e-3, 3e-2), (4, 2e-2, 2e-1)], ids=["f16x1", "bf16x1"])
+def test_single_piece_modes_step(hip, mode, loss_tol, grad_tol):
+    """the mixed-precision conv modes (operands rounded to ONE fp16 / bf16 piece, one MFMA per product, f32
+    accumulate; conv_precision 1 / 4).  Not the reference's arithmetic: a whole critic + generator step stays within the tolerance
+    that 11 / 8 significant operand bits allow (losses relative, gradients relative to each tensor's maximum), the head
+    (f32 MFMA GEMMs, VALU kernels) is unchanged."""
+    B, S, V = 8, 64, 50
+    old = hip.conv_precision
+    hip.conv_precision = mode
+    try:
+        gp, dp = O.init_params("G", V, S, perturb=0.05), O.init_params("D", V, S, perturb=0.05)
+        dp["W"] = dp["W"] * 25.0
+        images, labels, onehot = O.synth_batch(B, S, V)
+        noise0, noise1, alpha = O.synth_noise(B, 0), O.synth_noise(B, 1), O.synth_alpha(B, 0)
+        gs = GanStep(hip, V, S, B, lam=10.0, g_state=gp, d_state=dp)
+        assert gs.G.trunk.layers[1]["ws_layout"] == 1 and gs.G.trunk.layers[7]["ws_layout"] == 2      # the resident kernels serve it
+        d_adam, g_adam = O.new_adam_state(dp), O.new_adam_state(gp)
+        cost, aux, dgrads = O.d_step(gp, dp, d_adam, 1, images, onehot, noise0, alpha)
+        dl = gs.critic_step(images.cuda(), labels.cuda(), noise0.cuda(), alpha.reshape(B).cuda()).cpu()
+        assert abs(float(dl[0]) - float(cost)) <= loss_tol * max(1.0, abs(float(cost))), (dl, cost)
+        worst = max((tensor_err(gs.D.grads[n], g), n) for n, g in dgrads.items() if n != "decoder/bias")
+        print("mode %d critic gradients: worst rel err %.3e (%s)" % (mode, worst[0], worst[1]))
+        assert worst[0] < grad_tol, "critic gradient %s: rel err %.3e" % (worst[1], worst[0])
+        gs.D.arena.load_state_dict(dp)
+        gs.D.trunk.refresh_weights()
+        gcost, gaux, ggrads = O.g_step(gp, dp, g_adam, 1, images, noise1)
+        gl = gs.generator_step(images.cuda(), noise1.cuda()).cpu()
+        assert abs(-float(gl[3]) - float(gcost)) <= loss_tol * max(1.0, abs(float(gcost)))
+        worst = max((tensor_err(gs.G.grads[n], g), n) for n, g in ggrads.items())
+        print("mode %d generator gradients: worst rel err %.3e (%s)" % (mode, worst[0], worst[1]))
+        assert worst[0] < grad_tol, "generator gradient %s: rel err %.3e" % (worst[1], worst[0])
+    finally:
+        hip.conv_precision = old
