@@ -135,6 +135,30 @@ __global__ void gemm_slab_reduce_kernel(const float* __restrict__ slabs, float* 
   *c = s;
 }
 
+// Many slabs (the attention product: 128 slabs of 64 x 196): 32 outputs per workgroup, 8 thread groups each summing every 8th
+// slab, combined through LDS in group order (deterministic).  One thread per output walked 128 dependent 50-KB-strided loads.
+__global__ __launch_bounds__(256) void gemm_slab_reduce_wide_kernel(const float* __restrict__ slabs, float* __restrict__ C,
+                                                                    const float* __restrict__ bias, int M, int N, int ldc, int nsplit,
+                                                                    int accumulate) {
+  __shared__ float part[8][32];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + e, mn = (long long)M * N;
+  float s = 0.f;
+  if (i < mn)
+    for (int k = g; k < nsplit; k += 8) s += slabs[(long long)k * mn + i];
+  part[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < mn) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    float t = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][e];
+    float* c = C + (size_t)m * ldc + n;
+    if (accumulate) t += *c;
+    *c = t;
+  }
+}
+
 // smallest K range one workgroup of a split-K head GEMM takes.  These GEMMs are chains of dependent 32-deep slabs (f32 MFMA: 0.43 us
 // per slab per wave) on a handful of tiles: deeper splits shorten the chain (measured 256 -> 64: 53.16 -> 52.82 ms per G+D step)
 #ifndef SGG_GEMM_MIN_KCHUNK
@@ -201,8 +225,12 @@ static int gemm_run(int mode, int M, int N, int K, const float* A, int lda, cons
   SGG_LAUNCH_CHECK(name);
   if (p.nsplit > 1) {
     const long long n = (long long)M * N;
-    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(sgg_cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, C, bias, M,
-                       N, ldc, p.nsplit, accumulate);
+    if (p.nsplit >= 16)
+      hipLaunchKernelGGL(gemm_slab_reduce_wide_kernel, dim3(sgg_cdiv(n, 32)), dim3(256), 0, st, (const float*)workspace, C, bias, M,
+                         N, ldc, p.nsplit, accumulate);
+    else
+      hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(sgg_cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, C, bias, M,
+                         N, ldc, p.nsplit, accumulate);
     SGG_LAUNCH_CHECK(name);
   }
   return SGG_OK;
