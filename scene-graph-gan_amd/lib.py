@@ -138,7 +138,10 @@ class HipKernels:
         #   1          : only in encoder forwards that no backward follows (G in the critic update, D in the generator update) and
         #                for consumers with 64+ input channels: measured 53.4 vs 52.9 ms per step - still slower;
         #   2          : everywhere the halo-resident kernels allow: 60.2 vs 53.6 ms per step (wgrad +17 %, conv1_2 5x slower).
-        self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "0"))
+        # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = in the forward-only
+        # encoder passes, for consumers on the 128-column halo kernel (-0.43 ms per step); 2 = wherever the kernels allow (slower:
+        # DESIGN.md); 0 = never
+        self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "1"))
         assert self.conv_precision in (0, 1, 2, 3, 4, 6)       # 1 / 4: single-piece (mixed-precision) modes, include/sgg_hip.h
         self._amax_by_stream = {}
 

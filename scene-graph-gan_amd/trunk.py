@@ -141,13 +141,16 @@ class Trunk:
         staging) instead of a separate pass: the activation a_j is never written.  Needs the statistics partials from this layer's
         conv epilogue and a consumer served by the halo-resident kernels in the conv precision in force."""
         K = self.K
-        mode = getattr(K, "ln_fusion", 0)        # 0 off, 1 forward-only passes with 64+ consumer channels, 2 everywhere possible
+        mode = getattr(K, "ln_fusion", 0)        # 0 off, 1 forward-only passes, consumers on the 128-column halo kernel, 2 everywhere possible
         for j, lay in enumerate(self.layers):
             lay["fuse_ln"] = False
             if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and mode) or j + 1 >= len(self.layers) or lay["region"]:
                 continue
-            if mode == 1 and self.layers[j + 1]["cin"] < 64:
-                continue      # 32-channel consumers are staging-dominated: the prologue makes conv1_2 five times slower
+            if mode == 1 and self.layers[j + 1]["cout"] % 128 != 0:
+                # only consumers on the 128-column variant of the halo kernel: there the prologue costs 3-6 % of the convolution
+                # (14-45 us) against 36-144 us of LayerNorm apply pass; the four-block variants (64- / 32-column tiles) run 3-5x
+                # slower with it (64 -> 64 at 112x112: 0.22 -> 0.74 ms)
+                continue
             nxt = self.layers[j + 1]
             stats_ok = lay["tstats"] is not None and (lay["cin"] == 3 or (lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision
                                                                           and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])))
