@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
 
   f32x4 pre[NPASS][2];
   // issue the global loads of the next (tile, chunk) patch in flat order; past the last tile: out-of-range offsets (zeros)
-  auto stage_load = [&]() {
+  auto stage_load = [&]() __attribute__((always_inline)) {
     unsigned base[NB];
     int bbits[NB];
 #pragma unroll
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       }
     }
   };
-  auto stage_write = [&](unsigned char* dst) {
+  auto stage_write = [&](unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
       if constexpr (LNP) {

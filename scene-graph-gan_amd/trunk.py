@@ -147,10 +147,15 @@ class Trunk:
             if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and mode) or j + 1 >= len(self.layers) or lay["region"]:
                 continue
             if mode == 1 and self.layers[j + 1]["cout"] % 128 != 0:
-                # only consumers on the 128-column variant of the halo kernel: there the prologue costs 3-6 % of the convolution
-                # (14-45 us) against 36-144 us of LayerNorm apply pass; the four-block variants (64- / 32-column tiles) run 3-5x
-                # slower with it (64 -> 64 at 112x112: 0.22 -> 0.74 ms)
-                continue
+                # Consumers on the 128-column variant of the halo kernel pay 3-6 % (14-45 us at batch 64) against 36-144 us of
+                # LayerNorm apply pass: always a gain.  The four-block variants (64- / 32-column tiles) pay 50-60 us whatever the
+                # size: a gain only where the apply pass moves more than ~235 MB (2 x bytes at 5.7 TB/s > 1.5 x 55 us): conv1_2's
+                # input at batch 64 (411 MB: 144 us saved), not the 205 / 103 MB tensors.
+                nbytes = 4
+                for d in lay["out_shape"]:
+                    nbytes *= d
+                if 2.0 * nbytes / 5.7e12 <= 1.5 * 55e-6:
+                    continue
             nxt = self.layers[j + 1]
             stats_ok = lay["tstats"] is not None and (lay["cin"] == 3 or (lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision
                                                                           and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])))
