@@ -813,8 +813,8 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
                                    int precision, int w_split_layout, const float* amax_x, const float* amax_w, float* tile_stats,
                                    const float* ln_stats, const float* ln_gamma, const float* ln_beta, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
-  SGG_CHECK_ARG(!ln_stats || (w_split_layout == 1 && ln_gamma && ln_beta && Cin <= 512),
-                "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1 (halo-resident kernel), gamma, beta and Cin <= 512");
+  SGG_CHECK_ARG(!ln_stats || ((w_split_layout == 1 || w_split_layout == 3) && ln_gamma && ln_beta && Cin <= 512),
+                "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1 or 3 (halo-resident kernel), gamma, beta and Cin <= 512");
   SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 1, 2, 3, 4 or 6");
   SGG_CHECK_ARG(!sgg_prec_half(precision) || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 1 / 2 need the amax words");
   SGG_CHECK_ARG(!ln_stats || !sgg_prec_one(precision), "sgg_conv2d_nhwc_fwd: the LN prologue exists in the two-piece modes (2, 3) only");
@@ -856,12 +856,13 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
     HaloParams h;
     h.src = x; h.wfrag = w_split; h.bias = bias; h.out = y; h.amax_src = amax_x; h.amax_w = amax_w; h.tile_stats = tile_stats;
-    h.ln_stats = nullptr; h.ln_gamma = nullptr; h.ln_beta = nullptr;
+    h.ln_stats = ln_stats; h.ln_gamma = ln_gamma; h.ln_beta = ln_beta;
     h.B = B; h.H = Ho; h.W = Wo; h.C = 4 * Cin; h.N = Cout; h.bh = Ho / 8; h.bw = Wo / 8; h.nblk = B * h.bh * h.bw; h.flip = 0;
     h.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     h.w_bytes = (unsigned)((size_t)9 * 4 * Cin * Cout * sizeof(float));
     sgg_halo_dense_strides(h);
     h.in_rs = 2 * Wi * Cin; h.in_ps = 2 * Cin; h.in_cA = Wi * Cin; h.in_cB = Cin;     // chunk (qy, qx): x[2a + qy][2c + qx][0..32)
+    h.ln_nc = Cin;
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(s2d)");
     return SGG_OK;

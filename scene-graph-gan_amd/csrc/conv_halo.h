@@ -28,10 +28,12 @@ struct HaloParams {
   // (qy, qx): row stride 2*Wx*32, pixel stride 64, cA = Wx*32, cB = 32), its dgrad writes dx through the same view.
   int in_rs, in_ps, in_cA, in_cB;
   int out_rs, out_ps, out_nA, out_nB;
+  int ln_nc;              // LN prologue: real channels of the source (a power of two: C, or 32 for the space-to-depth view)
 };
 inline void sgg_halo_dense_strides(HaloParams& h) {
   h.in_rs = h.W * h.C; h.in_ps = h.C; h.in_cA = 64; h.in_cB = 32;
   h.out_rs = h.W * h.N; h.out_ps = h.N; h.out_nA = 64; h.out_nB = 32;
+  h.ln_nc = h.C;
 }
 
 // 1 if the halo kernel serves a 3x3 / stride-1 convolution over an H x W grid in this precision

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
                  (ch8 << 26) | ((it < ITEMS) << 28);
   }
   if constexpr (LNP) {
-    for (int c = tid; c < p.C; c += 256) {
+    for (int c = tid; c < p.ln_nc; c += 256) {      // (ln_nc = C, or 32 for the space-to-depth view: its four chunks are the same channels)
       lnp_s[c] = p.ln_gamma[c];
       lnp_s[512 + c] = p.ln_beta[c];
     }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
           mu = blk == k ? ld_mu[k] : mu;
           rs = blk == k ? ld_rs[k] : rs;
         }
-        const int cb = ld_cc * 32 + ((it_meta[j] >> 26) & 3) * 8;
+        const int cb = ((ld_cc * 32) & (p.ln_nc - 1)) + ((it_meta[j] >> 26) & 3) * 8;
         ln_elu8(pre[j][0], pre[j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad >> j) & 1);
       }
       u32x4 pl[P];

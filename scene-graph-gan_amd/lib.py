@@ -366,6 +366,12 @@ class HipKernels:
         return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
                 self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) == 1)
 
+    def ln_prologue_fwd_ok(self, k, stride, H, W, cin, cout):
+        """True if conv_fwd of this layer can apply the producing layer's LayerNorm + ELU itself (forward-only passes): the
+        halo-resident kernel, incl. conv1_3 through the space-to-depth view."""
+        return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
+                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 3))
+
     def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None):
         self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out)
         B, H, W, C = y.shape

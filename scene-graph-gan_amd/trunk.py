@@ -159,8 +159,9 @@ class Trunk:
             nxt = self.layers[j + 1]
             stats_ok = lay["tstats"] is not None and (lay["cin"] == 3 or (lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision
                                                                           and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])))
+            ok_fn = K.ln_prologue_fwd_ok if (mode == 1 and hasattr(K, "ln_prologue_fwd_ok")) else K.ln_prologue_ok
             lay["fuse_ln"] = bool(stats_ok and nxt["ws_fwd"] is not None and
-                                  K.ln_prologue_ok(nxt["k"], nxt["s"], nxt["hin"], nxt["win"], nxt["cin"], nxt["cout"]))
+                                  ok_fn(nxt["k"], nxt["s"], nxt["hin"], nxt["win"], nxt["cin"], nxt["cout"]))
 
     def refresh_weights(self):
         """Re-derive the HWOI forward layout after the parameters changed (Adam step / state-dict load)."""

@@ -680,6 +680,24 @@ def test_conv_s2d_fwd_dgrad(hip, ref, case, mode):
         hip.ln_elu_fwd(y, gamma, beta, a2, st2)
         close(st1, st2.cpu(), rtol=1e-6, what="stats from the s2d epilogue vs statistics pass")
         close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+        if mode in (2, 3):
+            # LN prologue through the space-to-depth view (forward-only passes): x is the producing layer's pre-LayerNorm output;
+            # the four 32-channel chunks of the view are the SAME 32 channels (gamma / beta index = channel within the chunk)
+            assert hip.ln_prologue_fwd_ok(5, 2, H, W, Ci, Co) and not hip.ln_prologue_ok(5, 2, H, W, Ci, Co)
+            y0 = rnd((B, H, W, Ci), 31, 2.0) + 0.7
+            y0[0] *= 3.0
+            g2, b2 = dev(1.0 + rnd((Ci,), 32, 0.3)), dev(rnd((Ci,), 33, 0.3))
+            y0d = dev(y0)
+            a = torch.empty((B, H, W, Ci), device="cuda")
+            st = torch.empty((B, 2), device="cuda")
+            am = torch.zeros(2, device="cuda")
+            hip.ln_elu_fwd(y0d, g2, b2, a, st, am[0:1])
+            hip.absmax(w3f, am[1:2])
+            y_u = torch.empty_like(y)
+            hip.conv_fwd(a, wd, wf, bd, y_u, 2, ws_f, am[0:1], am[1:2], None, 3)
+            y_f = torch.full(tuple(y.shape), float("nan"), device="cuda")
+            hip.conv_fwd(y0d, wd, wf, bd, y_f, 2, ws_f, am[0:1], am[1:2], None, 3, ln=(st, g2, b2))
+            close(y_f, y_u.cpu(), rtol=5e-6, what="s2d forward: LN prologue vs unfused")
     finally:
         hip.conv_precision = old
 
