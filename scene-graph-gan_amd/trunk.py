@@ -48,6 +48,23 @@ def plan_canvas(S):
     return [(canvas[j], off[j], true[j], canvas[j + 1], off[j + 1], true[j + 1]) for j in range(len(specs))]
 
 
+def ln_fusion_pays(out_shape, cout_next):
+    """(forward-only pass, pass followed by a backward): does applying this layer's LayerNorm + ELU in the consumer's patch staging
+    beat the LayerNorm apply pass?  Measured cost model at batch 64 (DESIGN.md "The LN prologue"), microseconds, MB = the
+    activation's bytes / 1e6:
+      saved      0.35 * MB                               read y + write a at 5.7 TB/s
+      forward    0.09 * MB * max(1, Cout / 128)          consumer on the 128-column variant (x staged once per 128 output columns)
+                 55                                      consumer on a four-block variant (64- / 32-column tiles): flat
+      wgrad      0.075 * MB * Cout / 64                  (x staged once per 64 output columns), only when a backward follows"""
+    mb = 4e-6
+    for d in out_shape:
+        mb *= d
+    saved = 0.35 * mb
+    fwd_cost = 0.09 * mb * max(1.0, cout_next / 128.0) if cout_next % 128 == 0 else 55.0
+    wgrad_cost = 0.075 * mb * cout_next / 64.0
+    return saved > 1.5 * fwd_cost, saved - fwd_cost - wgrad_cost > 10.0
+
+
 class Trunk:
     def __init__(self, K, arena, grad_views, B, S):
         self.K, self.B, self.S = K, B, S
@@ -137,31 +154,33 @@ class Trunk:
         return self.amax[row, j:j + 1] if self._f16() else None
 
     def _plan_ln_fusion(self):
-        """lay["fuse_ln"]: this layer's LayerNorm + ELU is applied by its consumer (the next convolution's forward and wgrad patch
-        staging) instead of a separate pass: the activation a_j is never written.  Needs the statistics partials from this layer's
-        conv epilogue and a consumer served by the halo-resident kernels in the conv precision in force."""
+        """lay["fuse_ln"] / lay["fuse_ln_bwd"]: this layer's LayerNorm + ELU is applied by its consumer (the next convolution's patch
+        staging) instead of a pass of its own, in encoder passes that no backward follows / that a backward follows (then the
+        activation a_j is never written and the consumer's wgrad applies the prologue as well).  Needs the statistics partials from
+        this layer's conv epilogue and a consumer on the halo-resident kernels in the conv precision in force.
+
+        K.ln_fusion: 0 off; 2 wherever the kernels allow (slower: DESIGN.md); 1 (default) where the measured cost model
+        (ln_fusion_pays) says it pays, per kind of pass."""
         K = self.K
-        mode = getattr(K, "ln_fusion", 0)        # 0 off, 1 forward-only passes, consumers on the 128-column halo kernel, 2 everywhere possible
+        mode = getattr(K, "ln_fusion", 0)
         for j, lay in enumerate(self.layers):
-            lay["fuse_ln"] = False
+            lay["fuse_ln"] = lay["fuse_ln_bwd"] = False
             if not (lay["has_ln"] and hasattr(K, "ln_prologue_ok") and mode) or j + 1 >= len(self.layers) or lay["region"]:
                 continue
-            if mode == 1 and self.layers[j + 1]["cout"] % 128 != 0:
-                # Consumers on the 128-column variant of the halo kernel pay 3-6 % (14-45 us at batch 64) against 36-144 us of
-                # LayerNorm apply pass: always a gain.  The four-block variants (64- / 32-column tiles) pay 50-60 us whatever the
-                # size: a gain only where the apply pass moves more than ~235 MB (2 x bytes at 5.7 TB/s > 1.5 x 55 us): conv1_2's
-                # input at batch 64 (411 MB: 144 us saved), not the 205 / 103 MB tensors.
-                nbytes = 4
-                for d in lay["out_shape"]:
-                    nbytes *= d
-                if 2.0 * nbytes / 5.7e12 <= 1.5 * 55e-6:
-                    continue
             nxt = self.layers[j + 1]
             stats_ok = lay["tstats"] is not None and (lay["cin"] == 3 or (lay["ws_fwd"] is not None and lay.get("ws_mode") == K.conv_precision
                                                                           and lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"])))
-            ok_fn = K.ln_prologue_fwd_ok if (mode == 1 and hasattr(K, "ln_prologue_fwd_ok")) else K.ln_prologue_ok
-            lay["fuse_ln"] = bool(stats_ok and nxt["ws_fwd"] is not None and
-                                  ok_fn(nxt["k"], nxt["s"], nxt["hin"], nxt["win"], nxt["cin"], nxt["cout"]))
+            if not (stats_ok and nxt["ws_fwd"] is not None):
+                continue
+            args = (nxt["k"], nxt["s"], nxt["hin"], nxt["win"], nxt["cin"], nxt["cout"])
+            both_ok = bool(K.ln_prologue_ok(*args))
+            fwd_ok = both_ok or bool(hasattr(K, "ln_prologue_fwd_ok") and K.ln_prologue_fwd_ok(*args))
+            if mode == 2:
+                lay["fuse_ln"] = lay["fuse_ln_bwd"] = both_ok
+                continue
+            pays_fwd, pays_bwd = ln_fusion_pays(lay["out_shape"], nxt["cout"])
+            lay["fuse_ln"] = fwd_ok and pays_fwd
+            lay["fuse_ln_bwd"] = both_ok and pays_bwd
 
     def refresh_weights(self):
         """Re-derive the HWOI forward layout after the parameters changed (Adam step / state-dict load)."""
@@ -191,7 +210,7 @@ class Trunk:
         layer may be applied by the consuming convolution's patch staging instead of a pass of its own (K.ln_fusion = 1)."""
         assert tuple(images.shape) == (self.B, self.S, self.S, 3), images.shape
         K = self.K
-        fuse_ok = getattr(K, "ln_fusion", 0) == 2 or (getattr(K, "ln_fusion", 0) == 1 and not for_backward)
+        fuse_key = "fuse_ln_bwd" if for_backward else "fuse_ln"
         self._fwd_for_backward = for_backward
         if self.img_canvas is not None:
             o = self.img_off
@@ -216,7 +235,7 @@ class Trunk:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             ln_in = None
             if lay["has_ln"]:
-                if fuse_ok and lay.get("fuse_ln") and ts is not None:
+                if lay.get(fuse_key) and ts is not None:
                     # statistics only; the consumer normalises y while it stages its patches (forward and wgrad)
                     K.ln_finalize(ts, lay["gamma"], lay["beta"], lay["stats"], self._am(0, j), lay["out_shape"][1] * lay["out_shape"][2])
                     ln_in = (lay["stats"], lay["gamma"], lay["beta"])
@@ -252,8 +271,6 @@ class Trunk:
         n = len(self.layers)
         f16 = self._f16()
         side = getattr(self, "wgrad_stream", None)
-        if side is not None and any(l.get("fused_now") for l in self.layers):
-            side = None
         main = torch.cuda.current_stream() if side is not None else None
         dybufs = [self._dY, self._dY2] if side is not None else [self._dY]
         reader_done = [None] * len(dybufs)        # event: the wgrad that reads this dY buffer has finished

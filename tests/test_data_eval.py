@@ -143,3 +143,21 @@ def test_recall_reference_literal_quirk():
     assert np.array_equal(ev._rank(scores, reference_literal=True)[:50], np.zeros(50, dtype=np.int64))
     assert ev.recalls(fake, scores, [fake[0].tolist()], reference_literal=True) == (1 / 50.0, 1 / 100.0)
     assert ev.recalls(fake, scores, [fake[5].tolist()], reference_literal=True) == (0.0, 0.0)
+
+
+def test_ln_fusion_cost_model_decisions_at_configs1():
+    """sgg_amd/trunk.py: ln_fusion_pays - which LayerNorms the default schedule hands to their consumer's patch staging at batch 64 /
+    224x224 (measured overheads, DESIGN.md "The LN prologue"): forward-only passes LN0, LN1, LN4, LN5, LN6, LN7, LN8 (LN6's consumer is
+    the band-resident kernel, which has no prologue: the trunk drops it); passes with a backward LN0, LN1, LN4, LN5, LN6 (LN1 / LN6: no
+    wgrad prologue on their consumers: dropped)."""
+    import sgg_amd  # noqa: F401
+    from sgg_amd.trunk import ln_fusion_pays
+    from sgg_amd.params import CONV_SPECS, same_pads
+    live = [c for c in CONV_SPECS if c[6]]
+    h, got = 224, {}
+    for idx, (i, cin, cout, k, s, has_ln, _) in enumerate(live[:-1]):
+        h = same_pads(h, k, s)[0]
+        got[i] = ln_fusion_pays((64, h, h, cout), live[idx + 1][2])
+    assert [i for i, v in got.items() if v[0]] == [0, 1, 4, 5, 6, 7, 8]
+    assert [i for i, v in got.items() if v[1]] == [0, 1, 4, 5, 6]
+    assert ln_fusion_pays((8, 64, 64, 32), 32) == (False, False)            # small tensors: the flat overhead never pays
