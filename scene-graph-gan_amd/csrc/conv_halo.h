@@ -81,6 +81,8 @@ struct S2Params {
   int pitch;              // Wo: slots per patch row (no halo columns: edge lanes read a zero slot)
   unsigned src_bytes, w_bytes;
   int gx;                 // workgroups per XCD (set by sgg_s2_launch)
+  int ksplit;             // 1, or 2: two workgroups per (band, n-tile), each contracting half of the channel chunks and ADDING its
+                          // partial into the zeroed output (a + b = b + a: still deterministic); set by sgg_s2_launch
 };
 // 1 if the band-resident kernel serves this 5x5 / stride-2 / SAME convolution (Hi, Wi = the full-resolution grid, both even;
 // C = contraction channels, N = output channels of the direction asked for)

@@ -38,6 +38,12 @@
 #ifndef S2_SMALL_ITEMS
 #define S2_SMALL_ITEMS 256            // at most this many 224-position work items: use 128-position bands instead
 #endif
+// Few work items (`downsampled` at batch 64: 56 bands x 4 n-tiles on 256 CUs): 0 = 128-position bands (392 items); 1 = 224-position
+// bands with the channel chunks split over two workgroups that ADD their partials into the zeroed output (448 items; a + b = b + a:
+// deterministic); 2 = both.  Measured 49.34 / 48.92 / 49.60 ms per G+D step (same box, two repetitions).
+#ifndef S2_KSPLIT_MODE
+#define S2_KSPLIT_MODE 1
+#endif
 #ifndef S2_SWZ
 #define S2_SWZ(slot) (((slot) >> 3) & 1)      // which 16-B half of a slot holds channels 0..7
 #endif
@@ -71,9 +77,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   __shared__ __attribute__((aligned(16))) int rowtab[2][BAND];      // byte offset of each band row in `out` (-1: past the end)
 
   // ---- persistent workgroup: XCD k owns a contiguous eighth of the bands; its p.gx workgroups walk (band, n-tile) pairs -----
-  const int ntn = p.N / S2_BN;
+  const int ntn = (p.N / S2_BN) * p.ksplit;                  // (n-tile, channel half) pairs: static per workgroup
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int nt = jx % ntn;
+  const int ntk = jx % ntn;
+  const int nt = ntk % (p.N / S2_BN), khalf = ntk / (p.N / S2_BN);
   const int bstride = p.gx / ntn;
   const int band_begin = (int)(((long long)xcd * p.nbands) >> 3) + jx / ntn;
   const int band_end = (int)(((long long)(xcd + 1) * p.nbands) >> 3);
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   const float sa = ldexpf(1.f, ea);
   const float us_a = ldexpf(1.f, -ea), us_b = ldexpf(1.f, -eb);
   const int Hp = p.Ho + 2;                                   // padded rows per image
-  const int nch = p.C >> 4;                                  // 16-channel chunks (even: C % 32 == 0)
+  const int nch = (p.C >> 4) / p.ksplit;                     // 16-channel chunks this workgroup contracts (even: host check)
+  const int cbeg = khalf * nch;                              // its first chunk
   const int nstage = 4 * nch;
 
   // ---- staging plan: item = (slot, half); static per thread: patch row / column and LDS byte offset -----------------------
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     if constexpr (DGRAD) { cls = s_stage / nch; cc = s_stage - cls * nch; }
     else { cc = s_stage >> 2; cls = s_stage & 3; }
     (void)cls;
+    cc += cbeg;
     unsigned uni = (unsigned)(cc * 64);
     if constexpr (!DGRAD) uni += (unsigned)((((cls < 2 ? 1 : 0) * 2 * p.Wo + ((cls & 1) ? 0 : 1)) * p.C) * 4);
 #pragma unroll
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   bool edge_l[MT], edge_r[MT];   // this lane's position is in the first / last column of its image row (lane masks)
   int cur = 0;               // patch buffer the current stage reads
   float bias_v = 0.f;
-  if constexpr (!DGRAD) bias_v = p.bias ? p.bias[n0 + i] : 0.f;
+  if constexpr (!DGRAD) bias_v = (p.bias && khalf == 0) ? p.bias[n0 + i] : 0.f;
 
   // A fragments go through a ring of three register sets: the fragments of row tile k+2 (of this tap or the next one) are
   // read from the resident patch while the MFMAs of tile k issue, so an LDS latency is exposed only at the start of a stage.
@@ -286,10 +295,17 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int4 o4 = *reinterpret_cast<const int4*>(&rowtab[tabsel][t * 32 + rq * 8 + 4 * h]);
-        if (o4.x >= 0) *reinterpret_cast<float*>(ob + o4.x) = acc[t][rq * 4 + 0];
-        if (o4.y >= 0) *reinterpret_cast<float*>(ob + o4.y) = acc[t][rq * 4 + 1];
-        if (o4.z >= 0) *reinterpret_cast<float*>(ob + o4.z) = acc[t][rq * 4 + 2];
-        if (o4.w >= 0) *reinterpret_cast<float*>(ob + o4.w) = acc[t][rq * 4 + 3];
+        if (p.ksplit > 1) {
+          if (o4.x >= 0) atomicAdd(reinterpret_cast<float*>(ob + o4.x), acc[t][rq * 4 + 0]);
+          if (o4.y >= 0) atomicAdd(reinterpret_cast<float*>(ob + o4.y), acc[t][rq * 4 + 1]);
+          if (o4.z >= 0) atomicAdd(reinterpret_cast<float*>(ob + o4.z), acc[t][rq * 4 + 2]);
+          if (o4.w >= 0) atomicAdd(reinterpret_cast<float*>(ob + o4.w), acc[t][rq * 4 + 3]);
+        } else {
+          if (o4.x >= 0) *reinterpret_cast<float*>(ob + o4.x) = acc[t][rq * 4 + 0];
+          if (o4.y >= 0) *reinterpret_cast<float*>(ob + o4.y) = acc[t][rq * 4 + 1];
+          if (o4.z >= 0) *reinterpret_cast<float*>(ob + o4.z) = acc[t][rq * 4 + 2];
+          if (o4.w >= 0) *reinterpret_cast<float*>(ob + o4.w) = acc[t][rq * 4 + 3];
+        }
       }
     if constexpr (!DGRAD) {
       if (p.tile_stats) {
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   // ---- prologue: first patch, first B fragments ----------------------------------------------------------------------------
   stage_band(s_band);
   stage_load();
-  load_b(std::integral_constant<int, 0>{}, 0, TAP0[0]);
+  load_b(std::integral_constant<int, 0>{}, cbeg, TAP0[0]);
   stage_write(lds);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -361,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     }
     // (the row table is read after at least one workgroup barrier: every stage ends with one)
     if constexpr (!DGRAD) {
-      for (int cc = 0; cc < nch; cc += 2) {
-        const bool last = cc + 2 >= nch;
+      for (int cc = cbeg; cc < cbeg + nch; cc += 2) {
+        const bool last = cc + 2 >= cbeg + nch;
         stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, cc, cc, TAP0[1]);
         stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cc, cc, TAP0[2]);
         stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, cc, cc, TAP0[3]);
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, cc + 1, cc + 1, TAP0[1]);
         stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, cc + 1, cc + 1, TAP0[2]);
         stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, cc + 1, cc + 1, TAP0[3]);
-        stage(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, cc + 1, last ? 0 : cc + 2, TAP0[0]);
+        stage(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, cc + 1, last ? cbeg : cc + 2, TAP0[0]);
       }
       epilogue(band, tabsel, 0);
     } else {
@@ -378,10 +394,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         constexpr int cls = decltype(cls_c)::value;
         constexpr int odd = cls_ntaps(cls) & 1;
         constexpr int ncls = (cls + 1) & 3;
-        for (int cc = 0; cc < nch; cc += 2) {
-          const bool last = cc + 2 >= nch;
+        for (int cc = cbeg; cc < cbeg + nch; cc += 2) {
+          const bool last = cc + 2 >= cbeg + nch;
           stage(cls_c, std::integral_constant<int, 0>{}, cc, cc + 1, TAP0[cls]);
-          stage(cls_c, std::integral_constant<int, odd>{}, cc + 1, last ? 0 : cc + 2, last ? TAP0[ncls] : TAP0[cls]);
+          stage(cls_c, std::integral_constant<int, odd>{}, cc + 1, last ? cbeg : cc + 2, last ? TAP0[ncls] : TAP0[cls]);
         }
         epilogue(band, tabsel, ((cls_qy(cls) * 2 * p.Wo + cls_qx(cls)) * p.N) * 4);
       };
@@ -424,11 +440,16 @@ int sgg_s2_stats_per_sample(int Ho, int Wo, int N) { return ((Ho * Wo) % S2_BAND
 
 void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st) {
   S2Params p = p_;
-  const int ntn = p.N / S2_BN;
-  // 224-position bands unless they give fewer work items than CUs (and no LayerNorm partials are asked for): then 128
-  const int mt = (!p.tile_stats && sgg_cdiv(p.M, S2_BAND) * ntn <= S2_SMALL_ITEMS) ? 4 : 7;
+  // 224-position bands unless they give fewer work items than CUs (and no LayerNorm partials are asked for): then 128-position
+  // bands (S2_KSPLIT_MODE 0), or 224-position bands with the channel chunks split over two workgroups (1), or both (2)
+  const bool small_ = !p.tile_stats && sgg_cdiv(p.M, S2_BAND) * (p.N / S2_BN) <= S2_SMALL_ITEMS;
+  const int mt = (small_ && S2_KSPLIT_MODE != 1) ? 4 : 7;
+  p.ksplit = (small_ && S2_KSPLIT_MODE != 0 && (p.C >> 4) % 4 == 0) ? 2 : 1;
+  if (p.ksplit > 1)
+    (void)hipMemsetAsync(p.out, 0, (size_t)(dgrad ? 4 : 1) * p.M * p.N * sizeof(float), st);
+  const int ntn = (p.N / S2_BN) * p.ksplit;
   p.nbands = sgg_cdiv(p.M, 32 * mt);
-  int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile) pairs an XCD owns
+  int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile, channel half) items an XCD owns
   int gx = per_xcd < 64 ? per_xcd : 64;            // two resident workgroups on each of its 32 CUs
   gx = sgg_cdiv(gx, ntn) * ntn;
   p.gx = gx;

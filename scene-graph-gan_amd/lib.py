@@ -272,8 +272,8 @@ class HipKernels:
                                                          "true" if self.conv_precision in (1, 4) else "false")
 
     def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True):
-        """(csrc/conv_s2.hip: sgg_s2_launch picks 128-position bands when 224-position ones give at most 256 work items)"""
-        mt = 4 if (not stats and -(-m_positions // 224) * (n_out // 128) <= 256) else 7
+        """(csrc/conv_s2.hip: 224-position bands; with at most 256 work items the channel chunks are split over two workgroups)"""
+        mt = 7
         return "conv_s2_kernel<%s,%s,%d,%s>" % ("true" if dgrad else "false", "true" if self.conv_precision in (1, 2) else "false", mt,
                                                 "true" if self.conv_precision in (1, 4) else "false")
 
