@@ -362,9 +362,10 @@ class HipKernels:
 
     def ln_prologue_ok(self, k, stride, H, W, cin, cout):
         """True if conv_fwd AND conv_wgrad of this layer can apply the producing layer's LayerNorm + ELU themselves
-        (halo-resident 3x3 stride-1 kernels of the split modes; the C ABI rejects the prologue elsewhere)."""
+        (halo-resident kernels of the split modes: 3x3 stride 1, and conv1_3 - forward through the space-to-depth view, wgrad in
+        its four parity-class launches; the C ABI rejects the prologue elsewhere)."""
         return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
-                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) == 1)
+                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 3))
 
     def ln_prologue_fwd_ok(self, k, stride, H, W, cin, cout):
         """True if conv_fwd of this layer can apply the producing layer's LayerNorm + ELU itself (forward-only passes): the

@@ -683,7 +683,7 @@ def test_conv_s2d_fwd_dgrad(hip, ref, case, mode):
         if mode in (2, 3):
             # LN prologue through the space-to-depth view (forward-only passes): x is the producing layer's pre-LayerNorm output;
             # the four 32-channel chunks of the view are the SAME 32 channels (gamma / beta index = channel within the chunk)
-            assert hip.ln_prologue_fwd_ok(5, 2, H, W, Ci, Co) and not hip.ln_prologue_ok(5, 2, H, W, Ci, Co)
+            assert hip.ln_prologue_fwd_ok(5, 2, H, W, Ci, Co) and hip.ln_prologue_ok(5, 2, H, W, Ci, Co)
             y0 = rnd((B, H, W, Ci), 31, 2.0) + 0.7
             y0[0] *= 3.0
             g2, b2 = dev(1.0 + rnd((Ci,), 32, 0.3)), dev(rnd((Ci,), 33, 0.3))
@@ -698,6 +698,14 @@ def test_conv_s2d_fwd_dgrad(hip, ref, case, mode):
             y_f = torch.full(tuple(y.shape), float("nan"), device="cuda")
             hip.conv_fwd(y0d, wd, wf, bd, y_f, 2, ws_f, am[0:1], am[1:2], None, 3, ln=(st, g2, b2))
             close(y_f, y_u.cpu(), rtol=5e-6, what="s2d forward: LN prologue vs unfused")
+            # ... and the filter gradient (four parity-class launches of the halo-resident wgrad kernel, each with the prologue)
+            amdy = torch.zeros(1, device="cuda")
+            hip.absmax(dyd, amdy)
+            dw_u = torch.full((5, 5, Ci, Co), float("nan"), device="cuda")
+            hip.conv_wgrad(a, dyd, dw_u, 2, am[0:1], amdy)
+            dw_f = torch.full((5, 5, Ci, Co), float("nan"), device="cuda")
+            hip.conv_wgrad(y0d, dyd, dw_f, 2, am[0:1], amdy, ln=(st, g2, b2))
+            close(dw_f, dw_u.cpu(), rtol=5e-6, what="conv1_3 wgrad: LN prologue vs unfused")
     finally:
         hip.conv_precision = old
 
