@@ -58,6 +58,22 @@ int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; ze
  * [3][3][4 * Cin][Cout] of sgg_conv_s2d_weights (11 of its 36 (tap, parity) slots are zero); weights in fragment order with
  * taps = 9 (forward: the HWOI transpose of that kernel, N = Cout, C = 4 * Cin; dgrad: the kernel itself, N = 4 * Cin, C = Cout). */
 int sgg_conv_s2d_weights(const float* w5 /* [5][5][Cin][Cout] */, float* w3 /* [3][3][4*Cin][Cout] */, int Cin, int Cout, void* stream);
+/* All of the above for every layer of one encoder after an optimiser step, in three launches (the per-layer entry points are
+ * ~45 five-microsecond launches per network): w_hwoi = the HWOI transpose; *amax = max|w| (precision 1 / 2; may be NULL
+ * otherwise); layout 3 (in either direction): w3 / w3_hwoi = the 9-tap space-to-depth kernel and its transpose; ws_fwd / ws_bwd
+ * (optional) = the pre-split operands of the forward / dgrad direction in layout_fwd / layout_bwd (sgg_conv_wsplit_layout; 0 =
+ * planes of sgg_conv_split_weights).  At most 16 layers per call; Cin == 3 layers need no preparation. */
+typedef struct {
+  const float* w;        /* HWIO [taps][Cin][Cout] */
+  float* w_hwoi;         /* [taps][Cout][Cin] */
+  float* w3;             /* layout 3 only, else NULL: [9][4*Cin][Cout] */
+  float* w3_hwoi;        /* layout 3 only, else NULL: [9][Cout][4*Cin] */
+  void* ws_fwd;          /* may be NULL */
+  void* ws_bwd;          /* may be NULL */
+  float* amax;
+  int taps, cin, cout, layout_fwd, layout_bwd;
+} sgg_conv_weight_desc;
+int sgg_conv_prepare_weights(const sgg_conv_weight_desc* layers, int n_layers, int precision, void* stream);
 /* The library reads no environment variables and keeps no mutable global state: every kernel choice is a function of the
  * arguments (w_split_layout here, `algo` of sgg_conv2d_nhwc_wgrad). */
 int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "sgg_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "sgg_conv_wsplit_layout": (_i, [_i] * 8),
     "sgg_conv_s2d_weights": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sgg_conv_prepare_weights": (_i, [_vp, _i, _i, _vp]),
     "sgg_conv_split_weights_frag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
@@ -71,6 +72,13 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+class ConvWeightDesc(ctypes.Structure):
+    """sgg_conv_weight_desc of include/sgg_hip.h."""
+    _fields_ = [("w", c_void_p), ("w_hwoi", c_void_p), ("w3", c_void_p), ("w3_hwoi", c_void_p), ("ws_fwd", c_void_p),
+                ("ws_bwd", c_void_p), ("amax", c_void_p), ("taps", c_int), ("cin", c_int), ("cout", c_int), ("layout_fwd", c_int),
+                ("layout_bwd", c_int)]
 
 
 class SggError(RuntimeError):
@@ -142,6 +150,8 @@ class HipKernels:
         # encoder passes, for consumers on the 128-column halo kernel (-0.43 ms per step); 2 = wherever the kernels allow (slower:
         # DESIGN.md); 0 = never
         self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "1"))
+        # A/B switch: 0 = re-derive the weight operand formats layer by layer (~45 launches per encoder) instead of prepare_weights
+        self.fused_weight_prep = os.environ.get("SGG_WEIGHT_PREP", "1") != "0"
         assert self.conv_precision in (0, 1, 2, 3, 4, 6)       # 1 / 4: single-piece (mixed-precision) modes, include/sgg_hip.h
         self._amax_by_stream = {}
 
@@ -258,6 +268,26 @@ class HipKernels:
         kh, kw, ci, co = w5.shape
         assert (kh, kw) == (5, 5) and tuple(w3.shape) == (3, 3, 4 * ci, co) and w5.is_contiguous() and w3.is_contiguous()
         self._check(self.lib.sgg_conv_s2d_weights(_p(w5), _p(w3), ci, co, self._stream()), "sgg_conv_s2d_weights")
+
+    def weight_descs(self, layers):
+        """layers: dicts with w, w_fwd, (w3, w3_fwd), ws_fwd, ws_bwd, amax (1-word view or None), ws_layout, ws_layout_bwd ->
+        a ctypes array of sgg_conv_weight_desc for prepare_weights (the tensors must stay alive and in place)."""
+        arr = (ConvWeightDesc * len(layers))()
+        for d, lay in zip(arr, layers):
+            w = lay["w"]
+            kh, kw, ci, co = w.shape
+            self._dev(w, lay["w_fwd"], lay.get("w3"), lay.get("w3_fwd"), lay.get("ws_fwd"), lay.get("ws_bwd"), lay.get("amax"))
+            d.w, d.w_hwoi = _p(w), _p(lay["w_fwd"])
+            d.w3, d.w3_hwoi = _p(lay.get("w3")), _p(lay.get("w3_fwd"))
+            d.ws_fwd, d.ws_bwd, d.amax = _p(lay.get("ws_fwd")), _p(lay.get("ws_bwd")), _p(lay.get("amax"))
+            d.taps, d.cin, d.cout, d.layout_fwd, d.layout_bwd = kh * kw, ci, co, lay["ws_layout"], lay["ws_layout_bwd"]
+        return arr
+
+    def prepare_weights(self, descs):
+        """Transposes, max|w|, space-to-depth kernels and both pre-split copies of every layer in `descs` (weight_descs): three
+        launches for a whole encoder (sgg_conv_prepare_weights)."""
+        self._check(self.lib.sgg_conv_prepare_weights(ctypes.addressof(descs), len(descs), self.conv_precision, self._stream()),
+                    "sgg_conv_prepare_weights")
 
     def conv_tile_stats_count(self, y_shape, cin, k=0, stride=0, layout=0):
         """(count, mean, M2) triples per sample the forward conv emits for this output shape in the current mode (0: none)."""

@@ -183,7 +183,33 @@ class Trunk:
             lay["fuse_ln_bwd"] = both_ok and pays_bwd
 
     def refresh_weights(self):
-        """Re-derive the HWOI forward layout after the parameters changed (Adam step / state-dict load)."""
+        """Re-derive the operand formats of the convolution kernels after the parameters changed (Adam step / state-dict load):
+        HWOI transposes, max|w| words, the space-to-depth kernel of conv1_3, both pre-split 16-bit copies.  One multi-tensor call
+        (three launches for the whole encoder) where the kernel set has it; per layer otherwise (the CPU reference kernels)."""
+        K = self.K
+        if hasattr(K, "prepare_weights") and getattr(K, "fused_weight_prep", True):
+            key = (K.conv_precision, getattr(K, "conv_halo", True))
+            if getattr(self, "_wdesc_key", None) != key:       # layouts depend on the precision in force: rebuild the table
+                todo = []
+                for j, lay in enumerate(self.layers):
+                    if lay["cin"] == 3:
+                        continue
+                    self._query_layouts(lay)
+                    if 3 in (lay["ws_layout"], lay["ws_layout_bwd"]) and "w3" not in lay:
+                        lay["w3"] = torch.empty((3, 3, 4 * lay["cin"], lay["cout"]), device=lay["w"].device, dtype=lay["w"].dtype)
+                        lay["w3_fwd"] = torch.empty((3, 3, lay["cout"], 4 * lay["cin"]), device=lay["w"].device, dtype=lay["w"].dtype)
+                    split = lay["ws_fwd"] is not None and K.conv_precision
+                    todo.append({"w": lay["w"], "w_fwd": lay["w_fwd"], "w3": lay.get("w3"), "w3_fwd": lay.get("w3_fwd"),
+                                 "ws_fwd": lay["ws_fwd"] if split else None, "ws_bwd": lay["ws_bwd"] if split else None,
+                                 "amax": self._am(2, j), "ws_layout": lay["ws_layout"] if split else 0,
+                                 "ws_layout_bwd": lay["ws_layout_bwd"] if split else 0})
+                self._wdesc, self._wdesc_key = K.weight_descs(todo), key
+            K.prepare_weights(self._wdesc)
+            for lay in self.layers:
+                if lay["cin"] != 3 and lay["ws_fwd"] is not None and K.conv_precision:
+                    lay["ws_mode"] = K.conv_precision
+            self._plan_ln_fusion()
+            return
         if self._f16():
             self.K.fill(self.amax[2], 0.0)
         for j, lay in enumerate(self.layers):

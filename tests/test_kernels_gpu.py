@@ -779,3 +779,53 @@ def test_layernorm_prologue_fwd_wgrad(hip, ref, case, mode):
         close(dw, dw_u.cpu(), rtol=5e-6, what="fused vs unfused wgrad")
     finally:
         hip.conv_precision = old
+
+
+@pytest.mark.parametrize("mode", [2, 3, 6, 0, 1], ids=["f16x3", "bf16x3", "bf16x6", "f32mfma", "f16x1"])
+def test_prepare_weights_equals_per_layer_entry_points(hip, mode):
+    """sgg_conv_prepare_weights (three launches for a whole encoder) writes bit for bit what sgg_hwio_to_hwoi + sgg_absmax +
+    sgg_conv_s2d_weights + sgg_conv_split_weights(_frag) write layer by layer, in every operand layout."""
+    old = hip.conv_precision
+    hip.conv_precision = mode
+    try:
+        # (k, cin, cout, layout_fwd, layout_bwd): planes, halo fragments, band fragments (25 taps), space-to-depth, mixed, ragged tiles
+        specs = [(3, 32, 32, 1, 1), (3, 64, 128, 1, 1), (5, 128, 128, 2, 2), (5, 32, 32, 3, 3), (3, 32, 64, 0, 0), (5, 256, 512, 2, 0), (3, 96, 40, 0, 0)]
+        if mode in (6, 0):
+            specs = [(k, ci, co, 0, 0) for (k, ci, co, _, _) in specs]
+        lays, refs = [], []
+        amax = torch.full((16,), 7.0, device="cuda")           # (stale values: the call must reset the words it owns)
+        amax_ref = torch.zeros(16, device="cuda")
+        for j, (k, ci, co, lf, lb) in enumerate(specs):
+            w = dev(rnd((k, k, ci, co), 100 + j, 0.1 * (j + 1)))
+            s2d = 3 in (lf, lb)
+            mk = lambda *shape: torch.full(shape, float("nan"), device="cuda")
+            lay = {"w": w, "w_fwd": mk(k, k, co, ci), "w3": mk(3, 3, 4 * ci, co) if s2d else None, "w3_fwd": mk(3, 3, co, 4 * ci) if s2d else None,
+                   "ws_fwd": torch.zeros((3, w.numel()), dtype=torch.int16, device="cuda") if mode else None,
+                   "ws_bwd": torch.zeros((3, w.numel()), dtype=torch.int16, device="cuda") if mode else None,
+                   "amax": amax[j:j + 1] if mode in (1, 2) else None, "ws_layout": lf, "ws_layout_bwd": lb}
+            lays.append(lay)
+            # the per-layer entry points
+            r = {"w_fwd": mk(k, k, co, ci)}
+            hip.hwio_to_hwoi(w, r["w_fwd"])
+            am = amax_ref[j:j + 1] if mode in (1, 2) else None
+            if am is not None:
+                hip.absmax(w, am)
+            if s2d:
+                r["w3"], r["w3_fwd"] = mk(3, 3, 4 * ci, co), mk(3, 3, co, 4 * ci)
+                hip.s2d_weights(w, r["w3"])
+                hip.hwio_to_hwoi(r["w3"], r["w3_fwd"])
+            if mode:
+                r["ws_fwd"], r["ws_bwd"] = torch.zeros_like(lay["ws_fwd"]), torch.zeros_like(lay["ws_bwd"])
+                hip.split_weights(r["w3_fwd"] if lf == 3 else r["w_fwd"], r["ws_fwd"], am, lf)
+                hip.split_weights(r["w3"] if lb == 3 else w, r["ws_bwd"], am, lb)
+            refs.append(r)
+        descs = hip.weight_descs(lays)
+        hip.prepare_weights(descs)
+        torch.cuda.synchronize()
+        for j, (lay, r) in enumerate(zip(lays, refs)):
+            for key, t in r.items():
+                assert torch.equal(lay[key], t), "layer %d (%s): %s differs" % (j, specs[j], key)
+        if mode in (1, 2):
+            assert torch.equal(amax[:len(specs)], amax_ref[:len(specs)]) and float(amax[len(specs)]) == 7.0
+    finally:
+        hip.conv_precision = old
