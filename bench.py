@@ -283,7 +283,7 @@ def main():
     for k in range(args.warmup):
         one_step(k)
     gs.flush()
-    dt, timing = timed(args.warmup, args.steps, not args.no_kernel_timing)
+    dt, timing = timed(args.warmup, args.steps, not args.no_kernel_timing, conv_only="mfma" if args.per_shape else True)
     d_losses, g_losses = gs.d_losses.cpu().tolist(), gs.g_losses.cpu().tolist()
     next_k = total_steps
     timing_hbm, hbm_steps = None, 2
@@ -311,6 +311,9 @@ def main():
             out["roofline_hbm"] = hbm_rooflines(summarise_timing(timing_hbm), hbm_steps)
             out["kernel_time_s"] = {s: round(v[3], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][3])}
             out["kernel_tflops"] = {s: round(v[1] / v[3] / 1e12, 2) for s, v in per.items() if v[3] > 0 and v[1] > 0}
+            # the other matrix kernels (filter gradients, conv1_1, attention product) are bracketed in the two extra steps only
+            out["kernel_tflops_extra_steps"] = {s: round(v[1] / v[3] / 1e12, 2) for s, v in summarise_timing(timing_hbm).items()
+                                                if v[3] > 0 and v[1] > 0 and s not in per}
             if args.per_shape:     # per (kernel, FLOPs per launch) = per layer and direction
                 shp = {}
                 for sym, fl, nb, e0, e1 in timing:

@@ -158,7 +158,10 @@ class HipKernels:
     def _timed(self, symbol, flops, fn, nbytes=0.0):
         """Run fn() between two HIP events on the launch stream when kernel timing is on (bench.py roofline legs).
         flops / nbytes: ALGORITHMIC work of the call (MFMA-bound convs: flops; HBM-bound kernels: bytes)."""
-        if self.timing is None or (self.timing_conv_only and flops <= 0.0):
+        # timing_conv_only: True = the forward / dgrad convolution launches only (the candidates of bench.py's `roofline`: every event
+        # pair costs ~5 us of the timed region), "mfma" = every call with algorithmic FLOPs, False = everything
+        if self.timing is None or (self.timing_conv_only == "mfma" and flops <= 0.0) or \
+                (self.timing_conv_only is True and not symbol.startswith(("conv_halo", "conv_s2", "conv_gather"))):
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(self.device))
