@@ -813,8 +813,8 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
                                    int precision, int w_split_layout, const float* amax_x, const float* amax_w, float* tile_stats,
                                    const float* ln_stats, const float* ln_gamma, const float* ln_beta, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
-  SGG_CHECK_ARG(!ln_stats || ((w_split_layout == 1 || w_split_layout == 3) && ln_gamma && ln_beta && Cin <= 512),
-                "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1 or 3 (halo-resident kernel), gamma, beta and Cin <= 512");
+  SGG_CHECK_ARG(!ln_stats || (w_split_layout >= 1 && w_split_layout <= 3 && ln_gamma && ln_beta && Cin <= 512),
+                "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1, 2 or 3 (resident kernels), gamma, beta and Cin <= 512");
   SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 1, 2, 3, 4 or 6");
   SGG_CHECK_ARG(!sgg_prec_half(precision) || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 1 / 2 need the amax words");
   SGG_CHECK_ARG(!ln_stats || !sgg_prec_one(precision), "sgg_conv2d_nhwc_fwd: the LN prologue exists in the two-piece modes (2, 3) only");
@@ -876,6 +876,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     SGG_CHECK_ARG(!tile_stats || sgg_s2_stats_per_sample(Ho, Wo, Cout) > 0, "sgg_conv2d_nhwc_fwd: tile_stats need Ho*Wo %% 224 == 0 here");
     S2Params q;
     q.src = x; q.wfrag = w_split; q.bias = bias; q.out = y; q.amax_src = amax_x; q.amax_w = amax_w; q.tile_stats = tile_stats;
+    q.ln_stats = ln_stats; q.ln_gamma = ln_gamma; q.ln_beta = ln_beta;
     q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cin; q.N = Cout; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo;
     q.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
@@ -958,6 +959,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
                   "sgg_conv2d_nhwc_dgrad: tensor exceeds 2 GiB");
     S2Params q;
     q.src = dy; q.wfrag = w_split; q.bias = nullptr; q.out = dx; q.amax_src = amax_dy; q.amax_w = amax_w; q.tile_stats = nullptr;
+    q.ln_stats = nullptr; q.ln_gamma = nullptr; q.ln_beta = nullptr;
     q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cout; q.N = Cin; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo;
     q.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));

@@ -74,6 +74,11 @@ struct S2Params {
   const float* amax_src;
   const float* amax_w;
   float* tile_stats;      // forward, optional: (count, mean, M2) per (band, 32 output channels)
+  // LN prologue (forward, two-piece modes, optional): src is the producing layer's PRE-LayerNorm output; the patch staging applies
+  // ELU((y - mean_b) * rstd_b * gamma_c + beta_c) (see HaloParams)
+  const float* ln_stats;
+  const float* ln_gamma;
+  const float* ln_beta;
   int B, Ho, Wo;          // the half-resolution grid (forward: output positions; dgrad: dy positions)
   int C, N;               // contraction channels, output channels
   int M;                  // B * Ho * Wo

@@ -69,9 +69,12 @@ constexpr int cls_ntaps(int cls) { return (cls_qy(cls) ? 3 : 2) * (cls_qx(cls) ?
 // MT = MFMA row tiles per band: 7 (224 positions), or 4 (128 positions) where 224-position bands would give fewer
 // (band, n-tile) work items than the chip has CUs (`downsampled` at batch 64: 56 bands x 4 n-tiles).
 // ONE: single-piece mode (precision 1 / 4): one 16-bit plane, one MFMA per product.
-template <bool DGRAD, bool HALF, int MT, bool ONE = false>
+// LNP: LN prologue (forward): src is the producing layer's pre-LayerNorm output, normalised + ELU'd while the patch is staged.
+template <bool DGRAD, bool HALF, int MT, bool ONE = false, bool LNP = false>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
+  static_assert(!LNP || (!DGRAD && !ONE), "the LN prologue exists for the forward of the two-piece modes");
   constexpr int P = ONE ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 1024 : 4];      // gamma[0..511], beta at +512 (C <= 512: host check)
   constexpr int BAND = 32 * MT;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * S2_PLB];
   __shared__ __attribute__((aligned(16))) int rowtab[2][BAND];      // byte offset of each band row in `out` (-1: past the end)
@@ -109,6 +112,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   // staging state (runs ahead of the compute state): band, stage inside the band, per-item source offsets of that band
   int s_band = band_begin, s_stage = 0;
   unsigned s_base[S2_NPASS];
+  int s_b[LNP ? S2_NPASS : 1];              // LN prologue: sample of each item of the band being staged
+  float ld_mu[LNP ? S2_NPASS : 1], ld_rs[LNP ? S2_NPASS : 1];     // ... and the (mean, rstd) / chunk of the patch in flight
+  int ld_cc = 0, ld_bad = 0;
   auto band_geometry = [&](int band, int& pg_first, int& nrows) __attribute__((always_inline)) {
     const int p0 = band * BAND;
     const int p1 = min(p0 + BAND, p.M) - 1;
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       const unsigned off = DGRAD ? (unsigned)((((b * p.Ho + a) * p.Wo + c) * p.C + half * 8) * 4)
                                  : (unsigned)((((b * 2 * p.Ho + 2 * a) * 2 * p.Wo + 2 * c) * p.C + half * 8) * 4);
       s_base[j] = ok ? off : SGG_OOB;
+      if constexpr (LNP) s_b[j] = b < p.B ? b : p.B - 1;
     }
   };
   f32x4 pre[S2_NPASS][2];
@@ -148,11 +155,17 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     cc += cbeg;
     unsigned uni = (unsigned)(cc * 64);
     if constexpr (!DGRAD) uni += (unsigned)((((cls < 2 ? 1 : 0) * 2 * p.Wo + ((cls & 1) ? 0 : 1)) * p.C) * 4);
+    if constexpr (LNP) { ld_cc = cc; ld_bad = 0; }
 #pragma unroll
     for (int j = 0; j < S2_NPASS; ++j) {
       const unsigned off = s_base[j] == SGG_OOB ? SGG_OOB : s_base[j] + uni;
       pre[j][0] = buf_load4(rs_src, off);
       pre[j][1] = buf_load4(rs_src, off + 16u);
+      if constexpr (LNP) {
+        ld_mu[j] = p.ln_stats[2 * s_b[j]];
+        ld_rs[j] = p.ln_stats[2 * s_b[j] + 1];
+        ld_bad |= (int)(s_base[j] == SGG_OOB) << j;
+      }
     }
     if (++s_stage == nstage) {
       s_stage = 0;
@@ -163,6 +176,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   auto stage_write = [&](unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < S2_NPASS; ++j) {
+      if constexpr (LNP) {
+        const int ch0 = ld_cc * 16 + (tid & 1) * 8;
+        ln_elu8(pre[j][0], pre[j][1], lnp_s + ch0, lnp_s + 512 + ch0, ld_mu[j], ld_rs[j], (ld_bad >> j) & 1);
+      }
       u32x4 pl[P];
       split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
       if (tid + 256 * j < 2 * S2_MAXSLOTS) {
@@ -339,6 +356,13 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   };
 
   // ---- prologue: first patch, first B fragments ----------------------------------------------------------------------------
+  if constexpr (LNP) {
+    for (int c = tid; c < p.C; c += 256) {
+      lnp_s[c] = p.ln_gamma[c];
+      lnp_s[512 + c] = p.ln_beta[c];
+    }
+    __syncthreads();
+  }
   stage_band(s_band);
   stage_load();
   load_b(std::integral_constant<int, 0>{}, cbeg, TAP0[0]);
@@ -442,7 +466,7 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
   S2Params p = p_;
   // 224-position bands unless they give fewer work items than CUs (and no LayerNorm partials are asked for): then 128-position
   // bands (S2_KSPLIT_MODE 0), or 224-position bands with the channel chunks split over two workgroups (1), or both (2)
-  const bool small_ = !p.tile_stats && sgg_cdiv(p.M, S2_BAND) * (p.N / S2_BN) <= S2_SMALL_ITEMS;
+  const bool small_ = !p.tile_stats && !p.ln_stats && sgg_cdiv(p.M, S2_BAND) * (p.N / S2_BN) <= S2_SMALL_ITEMS;
   const int mt = (small_ && S2_KSPLIT_MODE != 1) ? 4 : 7;
   p.ksplit = (small_ && S2_KSPLIT_MODE != 0 && (p.C >> 4) % 4 == 0) ? 2 : 1;
   if (p.ksplit > 1)
@@ -455,6 +479,11 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx));
   const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);
+  if (p.ln_stats) {       // LN prologue: forward, two-piece modes, 224-position bands (host checks in sgg_conv2d_nhwc_fwd)
+    if (half) hipLaunchKernelGGL((conv_s2_kernel<false, true, 7, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_s2_kernel<false, false, 7, false, true>), grid, dim3(256), 0, st, p);
+    return;
+  }
 #define SGG_S2(MT)                                                                                      \
   do {                                                                                                  \
     if (one) {                                                                                          \

@@ -150,6 +150,7 @@ class HipKernels:
         # encoder passes, for consumers on the 128-column halo kernel (-0.43 ms per step); 2 = wherever the kernels allow (slower:
         # DESIGN.md); 0 = never
         self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "1"))
+        self.ln_fusion_skip = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_SKIP", "").split(",") if v)   # A/B: conv indices
         # A/B switch: 0 = re-derive the weight operand formats layer by layer (~45 launches per encoder) instead of prepare_weights
         self.fused_weight_prep = os.environ.get("SGG_WEIGHT_PREP", "1") != "0"
         assert self.conv_precision in (0, 1, 2, 3, 4, 6)       # 1 / 4: single-piece (mixed-precision) modes, include/sgg_hip.h
@@ -304,11 +305,11 @@ class HipKernels:
                                                          "true" if n_in == 32 else "false", "true" if lnp else "false",
                                                          "true" if self.conv_precision in (1, 4) else "false")
 
-    def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True):
+    def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True, lnp=False):
         """(csrc/conv_s2.hip: 224-position bands; with at most 256 work items the channel chunks are split over two workgroups)"""
         mt = 7
-        return "conv_s2_kernel<%s,%s,%d,%s>" % ("true" if dgrad else "false", "true" if self.conv_precision in (1, 2) else "false", mt,
-                                                "true" if self.conv_precision in (1, 4) else "false")
+        return "conv_s2_kernel<%s,%s,%d,%s,%s>" % ("true" if dgrad else "false", "true" if self.conv_precision in (1, 2) else "false", mt,
+                                                   "true" if self.conv_precision in (1, 4) else "false", "true" if lnp else "false")
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0,
                  ln=None):
@@ -322,8 +323,8 @@ class HipKernels:
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
-                                                             self.halo_symbol(d[6], 4 * d[3]) if w_split_layout == 3 else
-                                                             self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None) if w_split_layout == 2 else
+                                                             self.halo_symbol(d[6], 4 * d[3], ln is not None) if w_split_layout == 3 else
+                                                             self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None, ln is not None) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
@@ -397,14 +398,17 @@ class HipKernels:
         """True if conv_fwd AND conv_wgrad of this layer can apply the producing layer's LayerNorm + ELU themselves
         (halo-resident kernels of the split modes: 3x3 stride 1, and conv1_3 - forward through the space-to-depth view, wgrad in
         its four parity-class launches; the C ABI rejects the prologue elsewhere)."""
-        return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
-                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 3))
+        if not (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512):
+            return False
+        lay = self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
+        # (layout 2: the band-resident forward has the prologue; its wgrad only on grids the 8x8-block halo kernel tiles)
+        return lay in (1, 3) or (lay == 2 and (H // 2) % 8 == 0 and (W // 2) % 8 == 0)
 
     def ln_prologue_fwd_ok(self, k, stride, H, W, cin, cout):
         """True if conv_fwd of this layer can apply the producing layer's LayerNorm + ELU itself (forward-only passes): the
-        halo-resident kernel, incl. conv1_3 through the space-to-depth view."""
+        resident kernels (halo incl. conv1_3 through the space-to-depth view, band-resident 5x5 stride 2)."""
         return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
-                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 3))
+                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 2, 3))
 
     def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None):
         self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out)

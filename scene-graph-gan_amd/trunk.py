@@ -179,6 +179,8 @@ class Trunk:
                 lay["fuse_ln"] = lay["fuse_ln_bwd"] = both_ok
                 continue
             pays_fwd, pays_bwd = ln_fusion_pays(lay["out_shape"], nxt["cout"])
+            if lay["i"] in getattr(K, "ln_fusion_skip", ()):      # (A/B switch SGG_LN_FUSION_SKIP of sgg_amd/lib.py)
+                pays_fwd = pays_bwd = False
             lay["fuse_ln"] = fwd_ok and pays_fwd
             lay["fuse_ln_bwd"] = both_ok and pays_bwd
 

@@ -147,9 +147,8 @@ def test_recall_reference_literal_quirk():
 
 def test_ln_fusion_cost_model_decisions_at_configs1():
     """sgg_amd/trunk.py: ln_fusion_pays - which LayerNorms the default schedule hands to their consumer's patch staging at batch 64 /
-    224x224 (measured overheads, DESIGN.md "The LN prologue"): forward-only passes LN0, LN1, LN4, LN5, LN6, LN7, LN8 (LN6's consumer is
-    the band-resident kernel, which has no prologue: the trunk drops it); passes with a backward LN0, LN1, LN4, LN5, LN6 (LN6:
-    dropped likewise)."""
+    224x224 (measured overheads, DESIGN.md "The LN prologue"): forward-only passes LN0, LN1, LN4, LN5, LN6, LN7, LN8; passes with a
+    backward LN0, LN1, LN4, LN5, LN6 (the trunk additionally asks the kernel set whether the consumer has the prologue)."""
     import sgg_amd  # noqa: F401
     from sgg_amd.trunk import ln_fusion_pays
     from sgg_amd.params import CONV_SPECS, same_pads

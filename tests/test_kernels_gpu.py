@@ -607,6 +607,24 @@ def test_conv_s2_fwd_dgrad(hip, ref, case, mode):
             hip.ln_elu_fwd(y, gamma, beta, a2, st2)
             close(st1, st2.cpu(), rtol=1e-6, what="stats from the s2 epilogue vs statistics pass")
             close(a1, a2.cpu(), rtol=1e-6, what="LN output")
+        if mode in (2, 3):
+            # LN prologue of the band-resident forward: x is the producing layer's pre-LayerNorm output; bands that cross image
+            # boundaries take each item's (mean, rstd) from its own sample
+            assert hip.ln_prologue_fwd_ok(5, 2, H, H, Ci, Co)
+            y0 = rnd((B, H, H, Ci), 31, 2.0) + 0.7
+            y0[0] *= 3.0
+            g2, b2 = dev(1.0 + rnd((Ci,), 32, 0.3)), dev(rnd((Ci,), 33, 0.3))
+            y0d = dev(y0)
+            a = torch.empty((B, H, H, Ci), device="cuda")
+            st = torch.empty((B, 2), device="cuda")
+            am = torch.zeros(2, device="cuda")
+            hip.ln_elu_fwd(y0d, g2, b2, a, st, am[0:1])
+            hip.absmax(wf, am[1:2])
+            y_u = torch.empty_like(y)
+            hip.conv_fwd(a, wd, wf, bd, y_u, 2, ws_f, am[0:1], am[1:2], None, 2)
+            y_f = torch.full(tuple(y.shape), float("nan"), device="cuda")
+            hip.conv_fwd(y0d, wd, wf, bd, y_f, 2, ws_f, am[0:1], am[1:2], None, 2, ln=(st, g2, b2))
+            close(y_f, y_u.cpu(), rtol=5e-6, what="s2 forward: LN prologue vs unfused %s" % (case,))
     finally:
         hip.conv_precision = old
 
