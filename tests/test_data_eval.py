@@ -160,3 +160,21 @@ def test_ln_fusion_cost_model_decisions_at_configs1():
     assert [i for i, v in got.items() if v[0]] == [0, 1, 4, 5, 6, 7, 8]
     assert [i for i, v in got.items() if v[1]] == [0, 1, 4, 5, 6]
     assert ln_fusion_pays((8, 64, 64, 32), 32) == (False, False)            # small tensors: the flat overhead never pays
+
+
+def test_canvas_plan_for_odd_image_sizes():
+    """sgg_amd/trunk.py: plan_canvas - the reference's 221 x 221 images (train.py:171; maps 221, 111, 56, 28, 14) sit at offsets
+    3 / 1 / 0 of even canvases 224 / 112 / 56 so that the canvas convolutions' own SAME padding coincides with the true one; sizes
+    that tile already, or whose canvas would exceed 1.3x the image, keep the plain grid."""
+    import sgg_amd  # noqa: F401
+    from sgg_amd.trunk import plan_canvas
+    plan = plan_canvas(221)
+    assert plan is not None and len(plan) == 12
+    assert plan[0][:3] == (224, 3, 221) and plan[0][3:] == (224, 3, 221)          # conv1_1: 3x3 stride 1 keeps canvas and offset
+    assert plan[2] == (224, 3, 221, 112, 1, 111)                                   # conv1_3: 5x5 stride 2, o_in = 2 * o_out + 1 (odd input)
+    assert plan[7] == (112, 1, 111, 56, 0, 56)                                     # conv2_5: odd 111 -> 56 at offset 0
+    assert plan[-1][3:] == (14, 0, 14)
+    assert plan_canvas(224) is None and plan_canvas(64) is None and plan_canvas(448) is None
+    assert plan_canvas(37) is None                                                 # canvas 48: 1.68x the pixels
+    p29 = plan_canvas(29)
+    assert p29[0][:3] == (32, 3, 29) and p29[2][3:] == (16, 1, 15) and p29[7][3:] == (8, 0, 8)
