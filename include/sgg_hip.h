@@ -126,6 +126,20 @@ int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamm
                               float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* dgamma == dbeta == NULL in sgg_layernorm_hwc_elu_bwd DEFERS the parameter-gradient reductions (dgamma, dbeta, dbias_prev): the
+ * partial sums stay in `workspace` (give every layer its own), and one launch of sgg_layernorm_hwc_bwd_finalize reduces up to 16
+ * layers at once (an encoder backward: eleven 20-microsecond launches off its critical path). */
+typedef struct {
+  const void* workspace;   /* as left by sgg_layernorm_hwc_elu_bwd(…, dgamma = NULL, …) with the same B, HW, C */
+  const float* gamma;
+  const float* stats;
+  float* dgamma;
+  float* dbeta;
+  float* dbias_prev;       /* may be NULL */
+  int B, HW, C, HW_valid;  /* HW_valid: pixels of the valid window (= HW without one) */
+} sgg_ln_finalize_desc;
+int sgg_layernorm_hwc_bwd_finalize(const sgg_ln_finalize_desc* layers, int n_layers, void* stream);
+
 /* ---- initial LSTM state: tf.reduce_mean(downsampled, axis=(1,2)) -------------------------------------------
  * generator_with_attention.py:76-77.  Rows r in [0,R) use image r % B (R/B passes share one feature map). */
 int sgg_spatial_mean_fwd(const float* ctx, float* out_c, int ldc, float* out_h, int ldh, int R, int B, int L, int C,

@@ -299,11 +299,11 @@ __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __rest
 
 // grid = C/32 workgroups; 1024 threads = 32 channels x 32 lanes over the samples
 #define LNF_BL 32
-__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ sspart, const float* __restrict__ chpart,
-                                                               const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ dbias, int B, int C, int G, int HW) {
-  extern __shared__ float sm[];  // [B][2] per-sample (s1/N, s2/N), then [LNF_BL][32][3] reduce
+__device__ __forceinline__ void ln_bwd_finalize_body(const float* __restrict__ sspart, const float* __restrict__ chpart,
+                                                     const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dbias, int B, int C, int G, int HW, int cgroup, float* sm) {
+  // sm: [B][2] per-sample (s1/N, s2/N), then [LNF_BL][32][3] reduce
   float* ssb = sm;
   float* redc = sm + 2 * B;
   const float invN = 1.f / ((float)HW * (float)C);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
   }
   __syncthreads();
   const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int c = cgroup * 32 + cl;
   float dg = 0.f, dbt = 0.f, dbs = 0.f;
   if (c < C) {
     const float gm = gamma[c];
@@ -346,6 +346,41 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
     dgamma[c] = r0; dbeta[c] = r1;
     if (dbias) dbias[c] = r2;
   }
+}
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ sspart, const float* __restrict__ chpart,
+                                                               const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dbias, int B, int C, int G, int HW) {
+  extern __shared__ float sm[];
+  ln_bwd_finalize_body(sspart, chpart, gamma, stats, dgamma, dbeta, dbias, B, C, G, HW, blockIdx.x, sm);
+}
+
+// The parameter-gradient reductions of SEVERAL LayerNorms in one launch (sgg_layernorm_hwc_bwd_finalize): an encoder backward
+// defers them (dgamma == NULL in sgg_layernorm_hwc_elu_bwd, one workspace per layer) - as launches of their own they are eleven
+// 16-workgroup kernels of 20 us each on the critical path of the backward.
+#define SGG_LNF_MAX 16
+struct LnfLayer {
+  const float* ws;         // the layer's workspace as sgg_layernorm_hwc_elu_bwd left it
+  const float* gamma;
+  const float* stats;
+  float* dgamma;
+  float* dbeta;
+  float* dbias;
+  int B, C, G, HW;         // HW: pixels of the valid window
+};
+struct LnfArgs {
+  LnfLayer L[SGG_LNF_MAX];
+  int first[SGG_LNF_MAX + 1];
+  int nl;
+};
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_batch_kernel(LnfArgs a) {
+  extern __shared__ float sm[];
+  int l = 0;
+  while (l + 1 < a.nl && (int)blockIdx.x >= a.first[l + 1]) ++l;
+  const LnfLayer& L = a.L[l];
+  const float* sspart = L.ws + (size_t)L.B * L.G * SGG_TS;
+  const float* chpart = sspart + (size_t)L.B * L.G * 2;
+  ln_bwd_finalize_body(sspart, chpart, L.gamma, L.stats, L.dgamma, L.dbeta, L.dbias, L.B, L.C, L.G, L.HW, blockIdx.x - a.first[l], sm);
 }
 
 template <bool MASK>
@@ -480,7 +515,7 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
                                          const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
                                          float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* ws,
                                          size_t ws_bytes, void* stream) {
-  SGG_CHECK_ARG(y && da && gamma && beta && stats && dy && dgamma && dbeta, "sgg_layernorm_hwc_elu_bwd: null pointer");
+  SGG_CHECK_ARG(y && da && gamma && beta && stats && dy && (!dgamma == !dbeta), "sgg_layernorm_hwc_elu_bwd: null pointer");
   int rc = ln_check("sgg_layernorm_hwc_elu_bwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
   LnMask mk;
@@ -498,8 +533,9 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
   else
     hipLaunchKernelGGL(ln_bwd_partial_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart,
                        g.N, C, g.G, g.cpg, mk);
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sspart,
-                     (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, hw_valid);
+  if (dgamma)      // (NULL: the caller reduces the partials later, several layers at once: sgg_layernorm_hwc_bwd_finalize)
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sspart,
+                       (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, hw_valid);
   if (W == 0)
     hipLaunchKernelGGL(ln_bwd_apply_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats,
                        (const float*)sspart, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
@@ -507,5 +543,38 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
     hipLaunchKernelGGL(ln_bwd_apply_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats,
                        (const float*)sspart, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
   SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd");
+  return SGG_OK;
+}
+
+struct sgg_ln_finalize_desc {      // mirrors include/sgg_hip.h
+  const void* workspace;
+  const float* gamma;
+  const float* stats;
+  float* dgamma;
+  float* dbeta;
+  float* dbias_prev;
+  int B, HW, C, HW_valid;
+};
+extern "C" int sgg_layernorm_hwc_bwd_finalize(const sgg_ln_finalize_desc* layers, int n, void* stream) {
+  SGG_CHECK_ARG(layers && n > 0 && n <= SGG_LNF_MAX, "sgg_layernorm_hwc_bwd_finalize: 1..%d layers", SGG_LNF_MAX);
+  LnfArgs a;
+  a.nl = n;
+  int tot = 0, maxB = 0;
+  for (int i = 0; i < n; ++i) {
+    const sgg_ln_finalize_desc& d = layers[i];
+    SGG_CHECK_ARG(d.workspace && d.gamma && d.stats && d.dgamma && d.dbeta && d.B > 0 && d.HW > 0 && d.C >= 4 && d.HW_valid > 0 &&
+                      d.HW_valid <= d.HW, "sgg_layernorm_hwc_bwd_finalize: layer %d: bad argument", i);
+    const LnGeom g = ln_geom(d.B, d.HW, d.C);
+    LnfLayer& L = a.L[i];
+    L.ws = (const float*)d.workspace; L.gamma = d.gamma; L.stats = d.stats; L.dgamma = d.dgamma; L.dbeta = d.dbeta; L.dbias = d.dbias_prev;
+    L.B = d.B; L.C = d.C; L.G = g.G; L.HW = d.HW_valid;
+    a.first[i] = tot;
+    tot += sgg_cdiv(d.C, 32);
+    if (d.B > maxB) maxB = d.B;
+  }
+  a.first[n] = tot;
+  const size_t sm = (size_t)(2 * maxB + LNF_BL * 32 * 3) * sizeof(float);
+  hipLaunchKernelGGL(ln_bwd_finalize_batch_kernel, dim3(tot), dim3(1024), sm, (hipStream_t)stream, a);
+  SGG_LAUNCH_CHECK("sgg_layernorm_hwc_bwd_finalize");
   return SGG_OK;
 }

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
     "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 9 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_bwd_finalize": (_i, [_vp, _i, _vp]),
     "sgg_layernorm_hwc_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -79,6 +80,12 @@ class ConvWeightDesc(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("w_hwoi", c_void_p), ("w3", c_void_p), ("w3_hwoi", c_void_p), ("ws_fwd", c_void_p),
                 ("ws_bwd", c_void_p), ("amax", c_void_p), ("taps", c_int), ("cin", c_int), ("cout", c_int), ("layout_fwd", c_int),
                 ("layout_bwd", c_int)]
+
+
+class LnFinalizeDesc(ctypes.Structure):
+    """sgg_ln_finalize_desc of include/sgg_hip.h."""
+    _fields_ = [("workspace", c_void_p), ("gamma", c_void_p), ("stats", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
+                ("dbias_prev", c_void_p), ("B", c_int), ("HW", c_int), ("C", c_int), ("HW_valid", c_int)]
 
 
 class SggError(RuntimeError):
@@ -410,15 +417,43 @@ class HipKernels:
         return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
                 self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 2, 3))
 
-    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None):
-        self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out)
+    def ln_workspace_bytes(self, shape):
+        B, H, W, C = shape
+        return self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
+
+    def ln_finalize_descs(self, layers):
+        """layers: dicts with ws (the layer's own workspace), gamma, stats, dgamma, dbeta, dbias, shape (B, H, W, C), region ->
+        ctypes array for ln_bwd_finalize (the tensors must stay alive and in place)."""
+        arr = (LnFinalizeDesc * len(layers))()
+        for d, lay in zip(arr, layers):
+            B, H, W, C = lay["shape"]
+            self._dev(lay["ws"], lay["gamma"], lay["stats"], lay["dgamma"], lay["dbeta"], lay.get("dbias"))
+            d.workspace, d.gamma, d.stats = _p(lay["ws"]), _p(lay["gamma"]), _p(lay["stats"])
+            d.dgamma, d.dbeta, d.dbias_prev = _p(lay["dgamma"]), _p(lay["dbeta"]), _p(lay.get("dbias"))
+            d.B, d.HW, d.C = B, H * W, C
+            d.HW_valid = H * W if lay.get("region") is None else lay["region"][2] * lay["region"][3]
+        return arr
+
+    def ln_bwd_finalize(self, descs):
+        """dgamma, dbeta and the producing convolutions' bias gradients of several LayerNorms whose ln_elu_bwd ran with
+        deferred reductions (dgamma=None, ws=...): one launch (sgg_layernorm_hwc_bwd_finalize)."""
+        self._check(self.lib.sgg_layernorm_hwc_bwd_finalize(ctypes.addressof(descs), len(descs), self._stream()),
+                    "sgg_layernorm_hwc_bwd_finalize")
+
+    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None, ws=None):
+        """dgamma = dbeta = None with a workspace `ws` of the layer's own: the parameter-gradient reductions are deferred to
+        ln_bwd_finalize."""
+        self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out, ws)
         B, H, W, C = y.shape
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
-        ws = self.workspace(need)
+        assert (dgamma is None) == (dbeta is None) and (dgamma is not None or ws is not None)
+        if ws is None:
+            ws = self.workspace(need)
+        assert ws.numel() * ws.element_size() >= need
         # algorithmic bytes: the reduction pass reads y and da, the apply pass reads them again and writes dy
         self._check(self._timed("ln_elu_bwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_bwd(
             _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma), _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C,
-            *self._region(region, H, W), _p(ws), ws.numel(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")
+            *self._region(region, H, W), _p(ws), ws.numel() * ws.element_size(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")
 
     # -- heads -----------------------------------------------------------------------------------------
     def spatial_mean_fwd(self, ctx, out_c, out_h):

@@ -136,6 +136,17 @@ class Trunk:
         # f16x3 mode: device words with max|tensor| of every conv operand (rows: activations a_j, gradients dy_j,
         # weights w_j), maintained by the producing kernels, so operands can be scaled into fp16 range without a host sync
         self.amax = torch.zeros((3, 16), device=dev, dtype=torch.float32)
+        # LayerNorm backward: the parameter-gradient reductions of all layers in ONE launch at the end of the encoder backward
+        # (K.ln_bwd_finalize), from per-layer workspaces that keep the partial sums until then
+        self._ln_fin = None
+        if hasattr(K, "ln_bwd_finalize"):
+            todo = []
+            for lay in self.layers:
+                if lay["has_ln"]:
+                    lay["ln_ws"] = torch.empty(K.ln_workspace_bytes(lay["out_shape"]), device=dev, dtype=torch.uint8)
+                    todo.append({"ws": lay["ln_ws"], "gamma": lay["gamma"], "stats": lay["stats"], "dgamma": lay["ggamma"], "dbeta": lay["gbeta"],
+                                 "dbias": lay["gb"], "shape": lay["out_shape"], "region": lay["region"]})
+            self._ln_fin = K.ln_finalize_descs(todo)
         self.refresh_weights()
 
     def _query_layouts(self, lay):
@@ -347,7 +358,10 @@ class Trunk:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"] if ws is not None else 0)
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])
-            if prev["region"] is not None:
+            if self._ln_fin is not None:
+                K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, None, None, None, self._am(1, j - 1) if f16 else None,
+                             region=prev["region"], ws=prev["ln_ws"])
+            elif prev["region"] is not None:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"],
                              *([self._am(1, j - 1)] if f16 else []), region=prev["region"])
             elif f16:
@@ -356,5 +370,7 @@ class Trunk:
             else:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"])
             dy, cur = dYp, nxt
+        if self._ln_fin is not None:
+            K.ln_bwd_finalize(self._ln_fin)       # dgamma, dbeta and the conv bias gradients of all eleven LayerNorms
         if side is not None:
             main.wait_stream(side)                # every filter gradient is complete before the optimiser / all-reduce reads it

@@ -847,3 +847,30 @@ def test_prepare_weights_equals_per_layer_entry_points(hip, mode):
             assert torch.equal(amax[:len(specs)], amax_ref[:len(specs)]) and float(amax[len(specs)]) == 7.0
     finally:
         hip.conv_precision = old
+
+
+def test_layernorm_bwd_deferred_finalize_equals_immediate(hip):
+    """sgg_layernorm_hwc_elu_bwd with dgamma = NULL leaves the partial sums in the layer's workspace; one
+    sgg_layernorm_hwc_bwd_finalize over several layers (one with a valid window) writes bit for bit what the immediate path writes."""
+    shapes = [((3, 16, 16, 32), None), ((2, 8, 8, 512), None), ((4, 12, 12, 128), (2, 1, 9, 10)), ((2, 40, 40, 64), None)]
+    lays, refs = [], []
+    for j, (shape, region) in enumerate(shapes):
+        B, H, W, C = shape
+        y, da = dev(rnd(shape, 70 + j, 2.0) + 0.3), dev(rnd(shape, 80 + j))
+        gamma, beta = dev(1.0 + rnd((C,), 90 + j, 0.2)), dev(rnd((C,), 95 + j, 0.2))
+        a, st = torch.empty(shape, device="cuda"), torch.empty((B, 2), device="cuda")
+        hip.ln_elu_fwd(y, gamma, beta, a, st, region=region)
+        mk = lambda: torch.full((C,), float("nan"), device="cuda")
+        dy1, dg1, db1, dbias1 = torch.empty(shape, device="cuda"), mk(), mk(), mk()
+        hip.ln_elu_bwd(y, da, gamma, beta, st, dy1, dg1, db1, dbias1, region=region)
+        ws = torch.empty(hip.ln_workspace_bytes(shape), dtype=torch.uint8, device="cuda")
+        dy2, dg2, db2, dbias2 = torch.empty(shape, device="cuda"), mk(), mk(), (mk() if j != 1 else None)
+        hip.ln_elu_bwd(y, da, gamma, beta, st, dy2, None, None, None, region=region, ws=ws)
+        assert torch.equal(dy1, dy2)
+        lays.append({"ws": ws, "gamma": gamma, "stats": st, "dgamma": dg2, "dbeta": db2, "dbias": dbias2, "shape": shape, "region": region})
+        refs.append((dg1, db1, dbias1))
+    hip.ln_bwd_finalize(hip.ln_finalize_descs(lays))
+    torch.cuda.synchronize()
+    for lay, (dg1, db1, dbias1) in zip(lays, refs):
+        assert torch.equal(lay["dgamma"], dg1) and torch.equal(lay["dbeta"], db1)
+        assert lay["dbias"] is None or torch.equal(lay["dbias"], dbias1)
