@@ -152,3 +152,48 @@ def test_ln_prologue_schedule_matches_unfused(hip):
         worst = max((float((a[which][k] - b[which][k]).abs().max() / (a[which][k].abs().max() + 1e-7)), k) for k in a[which])
         print("fused vs unfused gradients: worst rel diff %.3e (%s)" % worst)
         assert worst[0] < 3e-5, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ln_mode", [0, 2])
+def test_generator_encoder_reuse_within_iteration(hip, ln_mode):
+    """train.py's loop (GanStep.iteration(reuse_g_encoder=True)): every update of an iteration sees the same minibatch and G's weights
+    change only at its end, so G's encoder runs once per iteration instead of CRITIC_ITERS + 1 times.  Same kernels on the same
+    inputs: with the LN prologue off the weights after two iterations are BIT-equal to the recomputing schedule; with it on, the
+    critic updates read the with-backward fusion schedule instead of the forward-only one (ELU exp, |d| <= 1.2e-7)."""
+    B, S, V, CI = 8, 64, 50, 3
+    images, labels, _ = O.synth_batch(B, S, V)
+    images2, labels2, _ = O.synth_batch(B, S, V, seed_img=2, seed_lab=3)
+    old = hip.ln_fusion
+    res = {}
+    try:
+        hip.ln_fusion = ln_mode
+        for reuse in (False, True):
+            gp, dp = O.init_params("G", V, S, perturb=0.05), O.init_params("D", V, S, perturb=0.05)
+            dp["W"] = dp["W"] * 25.0
+            gs = GanStep(hip, V, S, B, lam=10.0, g_state=gp, d_state=dp)
+            calls = {"n": 0}
+            fwd = gs.G.trunk.forward
+
+            def counting(*a, _f=fwd, **k):
+                calls["n"] += 1
+                return _f(*a, **k)
+            gs.G.trunk.forward = counting
+            for it, (im, lb) in enumerate(((images, labels), (images2, labels2))):
+                im, lb = im.cuda().contiguous(), lb.cuda().contiguous()
+                noises = [O.synth_noise(B, 10 * it + i).cuda() for i in range(CI + 1)]
+                alphas = [O.synth_alpha(B, 10 * it + i).reshape(B).cuda() for i in range(CI)]
+                gs.train_iteration(im, lb, noises, alphas, critic_iters=CI, reuse_g_encoder=reuse)
+            gs.flush()
+            assert calls["n"] == (2 if reuse else 2 * (CI + 1)), calls
+            assert gs._g_reuse is None and not gs._g_reuse_armed
+            res[reuse] = ({k: v.clone().cpu() for k, v in gs.G.arena.views.items()}, {k: v.clone().cpu() for k, v in gs.D.arena.views.items()})
+    finally:
+        hip.ln_fusion = old
+    for net in (0, 1):
+        for k in res[False][net]:
+            a, b = res[False][net][k], res[True][net][k]
+            if ln_mode == 0:
+                assert torch.equal(a, b), (net, k, float((a - b).abs().max()))
+            else:
+                assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6, (net, k)

@@ -39,7 +39,7 @@ class SceneGraphGAN(object):
     ############################################################
     def __init__(self, checkpoints_dir, summaries_dir, path_to_ims_to_triples, path_to_vocab, path_to_word_embeddings,
                  path_to_image_means, path_to_image_stds, critic_iters, batch_size, lambda_, resume,
-                 synthetic=None, device=None, seed=0, two_streams=True):
+                 synthetic=None, device=None, seed=0, two_streams=True, reuse_g_encoder=True):
         # Hyperparameters (train.py:26-32)
         self.CRITIC_ITERS = int(critic_iters)
         self.BATCH_SIZE = int(batch_size)
@@ -51,6 +51,7 @@ class SceneGraphGAN(object):
         # two-stream schedule of step.GanStep (D's encoder beside G's forward, filter gradients beside the dgrad -> LayerNorm
         # chain): same kernels, bit-identical results (tests/test_concurrency_gpu.py), +4 % triples/s
         self.two_streams = bool(two_streams)
+        self.reuse_g_encoder = bool(reuse_g_encoder)
         self.checkpoints_dir, self.summaries_dir = checkpoints_dir, summaries_dir
         self.rank, self.world, local = dpmod.init_from_env()
         self.device = torch.device(device if device is not None else "cuda:%d" % local)
@@ -188,12 +189,15 @@ class SceneGraphGAN(object):
         loader = self._prefetcher(self.itr, n_it) if self.dataset is not None else None
         while self.itr < n_it:
             images, labels = next(loader) if loader is not None else self._next_batch(self.itr)
-            for _ in range(self.CRITIC_ITERS):                                      # train.py:364-365
+            # every update of an iteration sees the same minibatch (train.py:175-190) and G's weights change only at its end: G's
+            # encoder runs once per iteration (exact; 10 of 11 encoder forwards of G saved at CRITIC_ITERS = 10)
+            with self.step.iteration(reuse_g_encoder=self.reuse_g_encoder):
+                for _ in range(self.CRITIC_ITERS):                                  # train.py:364-365
+                    noise = torch.randn((B, 512), generator=gen).to(self.device)
+                    alpha = torch.rand((B,), generator=gen).to(self.device)
+                    self.step.critic_step(images, labels, noise, alpha)
                 noise = torch.randn((B, 512), generator=gen).to(self.device)
-                alpha = torch.rand((B,), generator=gen).to(self.device)
-                self.step.critic_step(images, labels, noise, alpha)
-            noise = torch.randn((B, 512), generator=gen).to(self.device)
-            self.step.generator_step(images, noise)                                 # train.py:368
+                self.step.generator_step(images, noise)                             # train.py:368
             self.itr += 1
             if log is not None and self.itr % log_every == 0:
                 d, g = self.step.d_losses.cpu().tolist(), self.step.g_losses.cpu().tolist()
@@ -295,6 +299,8 @@ if __name__ == "__main__":
     parser.add_argument("--synthetic", default=None, help="B,S,V: train on synthetic tensors of that shape (no dataset files)")
     parser.add_argument("--max_iterations", default=None, type=int)
     parser.add_argument("--single_stream", action="store_true", help="serial launch order (default: two HIP streams)")
+    parser.add_argument("--recompute_generator_encoder", action="store_true",
+                        help="run G's encoder in every update like the reference graph (default: once per iteration, same result)")
     args = parser.parse_args()
     params = vars(args)
 
@@ -306,5 +312,6 @@ if __name__ == "__main__":
                         path_to_word_embeddings=params["path_to_word_embeddings"],
                         path_to_image_means=params["path_to_image_means"], path_to_image_stds=params["path_to_image_stds"],
                         critic_iters=params["critic_iters"], batch_size=params["batch_size"], lambda_=params["lambda"],
-                        resume=params["resume"], synthetic=synthetic, two_streams=not params["single_stream"])
+                        resume=params["resume"], synthetic=synthetic, two_streams=not params["single_stream"],
+                        reuse_g_encoder=not params["recompute_generator_encoder"])
     gan.train(max_iterations=params["max_iterations"])
