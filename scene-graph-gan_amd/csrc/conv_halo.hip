@@ -40,6 +40,9 @@ extern "C" int sgg_halo_prof_read(unsigned long long* out, int reset) {
 #ifndef SGG_HALO_DB_MAX
 #define SGG_HALO_DB_MAX 65536   // two patch buffers when they fit in this many bytes of LDS (a gfx950 workgroup may use up to 160 KB; measured: see DESIGN.md)
 #endif
+#ifndef SGG_HALO_N64_PF
+#define SGG_HALO_N64_PF false
+#endif
 #define HALO_PITCH 12
 #define HALO_BLKB (10 * HALO_PITCH * 64)   // bytes of one plane of one block's patch
 
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     // A fragments of tap t+1 are read between the two k-steps of tap t (the in-kernel profile shows 11 % of a wave's time
     // in issue + wait of these reads when they sit in front of the MFMAs)
     PROF(const unsigned long long q2 = __builtin_readcyclecounter();)
+    SGG_PRIO_HI();
     mma_kstep(par_c, std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
     PROF(const unsigned long long q3 = __builtin_readcyclecounter();)
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
     __builtin_amdgcn_sched_barrier(0);
     PROF(const unsigned long long q4 = __builtin_readcyclecounter(); pc_lds += q4 - q3;)
     mma_kstep(par_c, std::integral_constant<int, 1>{});
+    SGG_PRIO_LO();
     __builtin_amdgcn_sched_barrier(0);
     PROF(pc_mfma += (__builtin_readcyclecounter() - q4) + (q3 - q2);)
   };
@@ -542,7 +547,7 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
     else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false>), grid, dim3(256), 0, st, p);                \
   } while (0)
   if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true);
-  else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false);
+  else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, SGG_HALO_N64_PF);
   else SGG_HALO(4, 32, 4, 1, true);
 #undef SGG_HALO
 }

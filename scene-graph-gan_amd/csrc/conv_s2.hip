@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     auto body = [&](auto ti_c) __attribute__((always_inline)) {
       constexpr int ti = decltype(ti_c)::value;
       constexpr int par = (par0 + ti) & 1;
-      if constexpr (ti + 1 < ntaps) {
+        if constexpr (ti + 1 < ntaps) {
         constexpr int njy = (ti + 1) / nx, njx = (ti + 1) % nx;
         load_b(std::integral_constant<int, par ^ 1>{}, cc, Axis<DGRAD>::k(qy, njy) * 5 + Axis<DGRAD>::k(qx, njx));
       } else {
@@ -278,10 +278,12 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         }
         mma_tile(std::integral_constant<int, k % 3>{}, t_c, std::integral_constant<int, par>{});
       };
+      SGG_PRIO_HI();
       tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{});
       tile(std::integral_constant<int, 3>{});
       if constexpr (MT > 4) { tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{}); tile(std::integral_constant<int, 6>{}); }
       static_assert(MT == 4 || MT == 7, "row tiles per band");
+      SGG_PRIO_LO();
       __builtin_amdgcn_sched_barrier(0);
     };
     body(std::integral_constant<int, 0>{}); body(std::integral_constant<int, 1>{});

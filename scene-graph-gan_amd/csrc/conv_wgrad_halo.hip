@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
     for (int s = 0; s < p.stages; ++s) {
       load1();
       __builtin_amdgcn_sched_barrier(0);
+      SGG_PRIO_HI();
       compute();
+      SGG_PRIO_LO();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       write1();
@@ -406,7 +408,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   for (int s = 0; s < p.stages; ++s) {
     if constexpr (PREF) stage_load();        // next stage's blocks (out-of-range offsets past the end: zeros, no traffic)
     __builtin_amdgcn_sched_barrier(0);
+    SGG_PRIO_HI();
     compute();
+    SGG_PRIO_LO();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (!PREF) stage_load();

@@ -116,3 +116,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 #endif
+
+// The resident convolution kernels raise the wave's issue priority over their MFMA clusters (s_setprio), so that the other resident
+// workgroup's wave in its staging phase does not take issue slots from the wave feeding the matrix pipe (-0.25 ms per step, same box,
+// two repetitions; raising it before the tap's B-fragment loads instead: the same).  -DSGG_MFMA_PRIO=0 builds without.
+#ifndef SGG_MFMA_PRIO
+#define SGG_MFMA_PRIO 1
+#endif
+#if SGG_MFMA_PRIO
+#define SGG_PRIO_HI() __builtin_amdgcn_s_setprio(SGG_MFMA_PRIO)
+#define SGG_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define SGG_PRIO_HI()
+#define SGG_PRIO_LO()
+#endif
