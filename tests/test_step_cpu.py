@@ -94,3 +94,32 @@ def test_critic_and_generator_step_match_oracle(setup):
     for name in dp:
         if not O.is_dead(name):
             assert rel_err(gs.D.arena.views[name], dp[name]) < 1e-8, "critic param after 2nd Adam: " + name
+
+
+def test_generator_encoder_reuse_within_iteration_is_exact():
+    """train.py's loop body (GanStep.iteration(reuse_g_encoder=True)): G's encoder once per iteration instead of CRITIC_ITERS + 1
+    times.  Same minibatch, unchanged G weights: every weight after two iterations equals the recomputing schedule's bit for bit."""
+    B, S, V, CI = 2, 32, 11, 2
+    res = {}
+    for reuse in (False, True):
+        gp, dp = make_states(V, S)
+        gs = GanStep(RefKernels(), V, S, B, lam=10.0, g_state=gp, d_state=dp, dtype=DT)
+        calls = {"n": 0}
+        fwd = gs.G.trunk.forward
+
+        def counting(*a, _f=fwd, **k):
+            calls["n"] += 1
+            return _f(*a, **k)
+        gs.G.trunk.forward = counting
+        for it in range(2):
+            images, labels, _ = O.synth_batch(B, S, V, seed_img=2 * it, seed_lab=2 * it + 1, dtype=DT)
+            noises = [O.synth_noise(B, 10 * it + i, DT) for i in range(CI + 1)]
+            alphas = [O.synth_alpha(B, 10 * it + i, DT).reshape(B) for i in range(CI)]
+            gs.train_iteration(images, labels, noises, alphas, critic_iters=CI, reuse_g_encoder=reuse)
+        gs.flush()
+        assert calls["n"] == (2 if reuse else 2 * (CI + 1))
+        assert gs._g_reuse is None and not gs._g_reuse_armed
+        res[reuse] = [{k: v.clone() for k, v in net.arena.views.items()} for net in (gs.G, gs.D)]
+    for a, b in zip(res[False], res[True]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
