@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
       const bool bad = !((it_meta[j] >> 28) & 1) | ((((it_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
       const unsigned off = bad ? SGG_OOB : b0 + it_rel[j];
       if constexpr (LNP) ld_bad |= (int)bad << j;
-      pre[j][0] = buf_load4(rs_src, off);
-      pre[j][1] = buf_load4(rs_src, off + 16u);
+      pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
+      pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
     }
     if (++s_cc == nch) {        // advance to this workgroup's next tile
       s_cc = 0;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const size_t so = ((size_t)(tm * 4 + (r >> 2)) * wn + (size_t)(r & 3) * p.out_ps + o_goff[tn]) * sizeof(float);   // scalar
-            *reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b) = acc[tm][tn][r];
+            sgg_out_store(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), acc[tm][tn][r]);
           }
     }
     if (p.tile_stats) {

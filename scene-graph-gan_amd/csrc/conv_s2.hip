@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
 #pragma unroll
     for (int j = 0; j < S2_NPASS; ++j) {
       const unsigned off = s_base[j] == SGG_OOB ? SGG_OOB : s_base[j] + uni;
-      pre[j][0] = buf_load4(rs_src, off);
-      pre[j][1] = buf_load4(rs_src, off + 16u);
+      pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
+      pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
       if constexpr (LNP) {
         ld_mu[j] = p.ln_stats[2 * s_b[j]];
         ld_rs[j] = p.ln_stats[2 * s_b[j] + 1];
@@ -320,10 +320,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
           if (o4.z >= 0) atomicAdd(reinterpret_cast<float*>(ob + o4.z), acc[t][rq * 4 + 2]);
           if (o4.w >= 0) atomicAdd(reinterpret_cast<float*>(ob + o4.w), acc[t][rq * 4 + 3]);
         } else {
-          if (o4.x >= 0) *reinterpret_cast<float*>(ob + o4.x) = acc[t][rq * 4 + 0];
-          if (o4.y >= 0) *reinterpret_cast<float*>(ob + o4.y) = acc[t][rq * 4 + 1];
-          if (o4.z >= 0) *reinterpret_cast<float*>(ob + o4.z) = acc[t][rq * 4 + 2];
-          if (o4.w >= 0) *reinterpret_cast<float*>(ob + o4.w) = acc[t][rq * 4 + 3];
+          if (o4.x >= 0) sgg_out_store(reinterpret_cast<float*>(ob + o4.x), acc[t][rq * 4 + 0]);
+          if (o4.y >= 0) sgg_out_store(reinterpret_cast<float*>(ob + o4.y), acc[t][rq * 4 + 1]);
+          if (o4.z >= 0) sgg_out_store(reinterpret_cast<float*>(ob + o4.z), acc[t][rq * 4 + 2]);
+          if (o4.w >= 0) sgg_out_store(reinterpret_cast<float*>(ob + o4.w), acc[t][rq * 4 + 3]);
         }
       }
     if constexpr (!DGRAD) {

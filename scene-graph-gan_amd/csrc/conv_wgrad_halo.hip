@@ -196,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
       const unsigned off = bad ? SGG_OOB : (isx ? xbase : dbase) + rel;
       const int slot = (DY_LATE && !isx) ? jj - XP : jj;
       if (isx) {
-        pre[slot][0] = buf_load4(rs_x, off);
-        pre[slot][1] = buf_load4(rs_x, off + 16u);
+        pre[slot][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off);
+        pre[slot][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off + 16u);
       } else {
-        pre[slot][0] = buf_load4(rs_dy, off);
-        pre[slot][1] = buf_load4(rs_dy, off + 16u);
+        pre[slot][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off);
+        pre[slot][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off + 16u);
       }
     }
     if constexpr (part != 1) {
@@ -249,11 +249,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
         if constexpr (LNP) ld_bad |= (int)bad << j;
         const unsigned off = bad ? SGG_OOB : (isx ? xbase : dbase) + it_rel[j];
         if (isx) {
-          pre[j][0] = buf_load4(rs_x, off);
-          pre[j][1] = buf_load4(rs_x, off + 16u);
+          pre[j][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off);
+          pre[j][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off + 16u);
         } else {
-          pre[j][0] = buf_load4(rs_dy, off);
-          pre[j][1] = buf_load4(rs_dy, off + 16u);
+          pre[j][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off);
+          pre[j][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off + 16u);
         }
       }
       // advance this slot to the next stage's block

@@ -130,3 +130,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #define SGG_PRIO_HI()
 #define SGG_PRIO_LO()
 #endif
+
+// The convolution epilogues store their output tiles with the nontemporal hint (the tensors are far larger than the L2 of an XCD and
+// are next read by another kernel): -0.2 ms per step, four same-box repetitions.  -DSGG_CONV_NT_STORE=0 builds without.
+#ifndef SGG_CONV_NT_STORE
+#define SGG_CONV_NT_STORE 1
+#endif
+__device__ __forceinline__ void sgg_out_store(float* p, float v) {
+#if SGG_CONV_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}

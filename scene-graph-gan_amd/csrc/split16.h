@@ -5,6 +5,17 @@
 
 #define SGG_OOB 0x80000000u
 
+// activation patch loads of the resident convolution kernels: -DSGG_PATCH_LOAD_AUX=2 adds the nontemporal hint (measured: DESIGN.md section 8)
+#ifndef SGG_PATCH_LOAD_AUX
+#define SGG_PATCH_LOAD_AUX 0
+#endif
+#ifndef SGG_WGRAD_LOAD_AUX
+#define SGG_WGRAD_LOAD_AUX 0
+#endif
+template <int AUX>
+__device__ __forceinline__ f32x4 buf_load4_aux(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, AUX));
+}
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
 }
