@@ -140,6 +140,7 @@ class HipKernels:
         self._ws_by_stream = {}
         self.timing = None      # bench.py sets this to a list: launches are then bracketed by HIP events
         self.timing_conv_only = False   # True: only the MFMA-bound convolution calls are bracketed (the timed region of bench.py)
+        self.timing_symbols = None      # with timing_conv_only True: bracket only these kernel symbols (bench.py: the dominant one)
         # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
         #   2 (default) f32 operands scaled by a per-tensor power of two and split into two fp16 pieces (22 significant
         #               bits), 3 fp16 MFMAs per product, f32 accumulate: error against fp64 equal to the native f32 path's;
@@ -148,11 +149,6 @@ class HipKernels:
         #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance).
         self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
         self.conv_halo = os.environ.get("SGG_CONV_HALO", "1") != "0"
-        # LayerNorm + ELU applied by the consuming 3x3 convolution's patch staging (trunk.py), the activation is never written:
-        #   0 (default): off - every LayerNorm is a pass of its own (statistics from the producing conv's epilogue);
-        #   1          : only in encoder forwards that no backward follows (G in the critic update, D in the generator update) and
-        #                for consumers with 64+ input channels: measured 53.4 vs 52.9 ms per step - still slower;
-        #   2          : everywhere the halo-resident kernels allow: 60.2 vs 53.6 ms per step (wgrad +17 %, conv1_2 5x slower).
         # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = in the forward-only
         # encoder passes, for consumers on the 128-column halo kernel (-0.43 ms per step); 2 = wherever the kernels allow (slower:
         # DESIGN.md); 0 = never
@@ -169,7 +165,8 @@ class HipKernels:
         # timing_conv_only: True = the forward / dgrad convolution launches only (the candidates of bench.py's `roofline`: every event
         # pair costs ~5 us of the timed region), "mfma" = every call with algorithmic FLOPs, False = everything
         if self.timing is None or (self.timing_conv_only == "mfma" and flops <= 0.0) or \
-                (self.timing_conv_only is True and not symbol.startswith(("conv_halo", "conv_s2", "conv_gather"))):
+                (self.timing_conv_only is True and (not symbol.startswith(("conv_halo", "conv_s2", "conv_gather")) or
+                                                   (self.timing_symbols is not None and symbol not in self.timing_symbols))):
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(self.device))
