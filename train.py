@@ -185,7 +185,7 @@ class SceneGraphGAN(object):
         n_it = max_iterations if max_iterations is not None else getattr(self, "max_iterations", 1000)
         gen = torch.Generator().manual_seed(self.seed + 7 + self.rank)
         log = open(os.path.join(self.summaries_dir, "losses.jsonl"), "a") if self.rank == 0 else None
-        B, t0 = self.BATCH_SIZE, time.time()
+        B, t0, itr0 = self.BATCH_SIZE, time.time(), self.itr
         loader = self._prefetcher(self.itr, n_it) if self.dataset is not None else None
         while self.itr < n_it:
             images, labels = next(loader) if loader is not None else self._next_batch(self.itr)
@@ -201,7 +201,7 @@ class SceneGraphGAN(object):
             self.itr += 1
             if log is not None and self.itr % log_every == 0:
                 d, g = self.step.d_losses.cpu().tolist(), self.step.g_losses.cpu().tolist()
-                rate = B * self.world * self.itr / (time.time() - t0)
+                rate = B * self.world * (self.itr - itr0) / (time.time() - t0)      # of this run (a resumed run starts at itr0 > 0)
                 rec = {"itr": self.itr, "disc_loss": d[0], "gen_loss": -g[3], "gp": d[2], "triples_per_s": rate}
                 log.write(json.dumps(rec) + "\n"); log.flush()
                 print(rec)
