@@ -40,9 +40,6 @@ extern "C" int sgg_halo_prof_read(unsigned long long* out, int reset) {
 #ifndef SGG_HALO_DB_MAX
 #define SGG_HALO_DB_MAX 65536   // two patch buffers when they fit in this many bytes of LDS (a gfx950 workgroup may use up to 160 KB; measured: see DESIGN.md)
 #endif
-#ifndef SGG_HALO_N64_PF
-#define SGG_HALO_N64_PF false
-#endif
 #define HALO_PITCH 12
 #define HALO_BLKB (10 * HALO_PITCH * 64)   // bytes of one plane of one block's patch
 
@@ -518,7 +515,12 @@ int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, 
          sgg_prec_resident(precision);
 }
 
-int sgg_halo_stats_cols(int N) { return (N % 64 == 0) ? 64 : 32; }
+// 64-column layers run on two-block workgroups (2 x 2 waves of 64 pixels x 32 columns, two patch buffers, prefetch); -DSGG_HALO_N64_NB2=0:
+// four-block ones (4 waves of 64 x 64, one buffer, no prefetch: 0.1 ms per step slower)
+#ifndef SGG_HALO_N64_NB2
+#define SGG_HALO_N64_NB2 1
+#endif
+int sgg_halo_stats_cols(int N) { return (N % (SGG_HALO_N64_NB2 ? 128 : 64) == 0) ? 64 : 32; }
 
 void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
   HaloParams p = p_;
@@ -547,7 +549,8 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
     else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false>), grid, dim3(256), 0, st, p);                \
   } while (0)
   if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true);
-  else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, SGG_HALO_N64_PF);
+  else if (p.N % 64 == 0 && SGG_HALO_N64_NB2) SGG_HALO(2, 64, 2, 2, true);
+  else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false);      // (with PREFETCH: 35 spilled VGPRs at the 256-register budget of two waves per SIMD)
   else SGG_HALO(4, 32, 4, 1, true);
 #undef SGG_HALO
 }

@@ -154,6 +154,8 @@ class HipKernels:
         # DESIGN.md); 0 = never
         self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "1"))
         self.ln_fusion_skip = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_SKIP", "").split(",") if v)   # A/B: conv indices
+        self.ln_fusion_force = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_FORCE", "").split(",") if v)  # A/B: forward-only passes
+        self.ln_fusion_force_bwd = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_FORCE_BWD", "").split(",") if v)  # A/B: passes with backward
         # A/B switch: 0 = re-derive the weight operand formats layer by layer (~45 launches per encoder) instead of prepare_weights
         self.fused_weight_prep = os.environ.get("SGG_WEIGHT_PREP", "1") != "0"
         assert self.conv_precision in (0, 1, 2, 3, 4, 6)       # 1 / 4: single-piece (mixed-precision) modes, include/sgg_hip.h

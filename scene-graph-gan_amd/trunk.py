@@ -53,16 +53,19 @@ def ln_fusion_pays(out_shape, cout_next):
     beat the LayerNorm apply pass?  Measured cost model at batch 64 (DESIGN.md "The LN prologue"), microseconds, MB = the
     activation's bytes / 1e6:
       saved      0.35 * MB                               read y + write a at 5.7 TB/s
-      forward    0.09 * MB * max(1, Cout / 128)          consumer on the 128-column variant (x staged once per 128 output columns)
-                 55                                      consumer on a four-block variant (64- / 32-column tiles): flat
-      wgrad      0.075 * MB * Cout / 64                  (x staged once per 64 output columns), only when a backward follows"""
+      forward    0.09 * MB * max(1, Cout / 128)          consumer on a two-block variant (128- / 64-column tiles; x staged once per 128
+                                                         output columns)
+                 55                                      consumer on the four-block variant (32-column tiles): flat
+      wgrad      0.075 * MB * Cout / 64                  (x staged once per 64 output columns), only when a backward follows; with a
+                                                         64-column consumer the pass with backward measured no gain (47.77 / 47.86 vs
+                                                         47.71 / 47.82 ms per step): forward-only there"""
     mb = 4e-6
     for d in out_shape:
         mb *= d
     saved = 0.35 * mb
-    fwd_cost = 0.09 * mb * max(1.0, cout_next / 128.0) if cout_next % 128 == 0 else 55.0
+    fwd_cost = 0.09 * mb * max(1.0, cout_next / 128.0) if cout_next % 64 == 0 else 55.0
     wgrad_cost = 0.075 * mb * cout_next / 64.0
-    return saved > 1.5 * fwd_cost, saved - fwd_cost - wgrad_cost > 10.0
+    return saved > 1.5 * fwd_cost, cout_next != 64 and saved - fwd_cost - wgrad_cost > 10.0
 
 
 class Trunk:
@@ -192,6 +195,10 @@ class Trunk:
             pays_fwd, pays_bwd = ln_fusion_pays(lay["out_shape"], nxt["cout"])
             if lay["i"] in getattr(K, "ln_fusion_skip", ()):      # (A/B switch SGG_LN_FUSION_SKIP of sgg_amd/lib.py)
                 pays_fwd = pays_bwd = False
+            if lay["i"] in getattr(K, "ln_fusion_force", ()):     # (A/B switch SGG_LN_FUSION_FORCE)
+                pays_fwd = True
+            if lay["i"] in getattr(K, "ln_fusion_force_bwd", ()):
+                pays_bwd = True
             lay["fuse_ln"] = fwd_ok and pays_fwd
             lay["fuse_ln_bwd"] = both_ok and pays_bwd
 

@@ -457,7 +457,8 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
         close(y, y_g.cpu(), rtol=5e-6 if mode in (2, 3) else 2.0 * tol, what="halo vs gather")
         # LayerNorm partial statistics from the halo epilogue
         nts = hip.conv_tile_stats_count((B, H, W, Co), Ci, 3, 1, 1)
-        assert nts == (H * W // 64) * (Co // (64 if Co % 64 == 0 else 32))
+        assert nts in ((H * W // 64) * (Co // (64 if Co % 64 == 0 else 32)),
+                       (H * W // 64) * (Co // (64 if Co % 128 == 0 else 32)))        # (second form: -DSGG_HALO_N64_NB2 builds)
         ts = torch.full((B, nts, 4), float("nan"), device="cuda")
         y2 = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y2, 1, ws_f, tile_stats=ts, w_split_layout=1)
