@@ -305,9 +305,9 @@ class HipKernels:
                                                        layout)
 
     def halo_symbol(self, n_out, n_in, lnp=False):
-        tile = "2,128,2,2" if n_out % 128 == 0 else ("4,64,4,1" if n_out % 64 == 0 else "4,32,4,1")
-        return "conv_halo3_kernel<%s,%s,%s,%s,%s,%s>" % (tile, "true" if self.conv_precision in (1, 2) else "false",
-                                                         "true" if (n_out % 128 == 0 or n_out % 64 != 0) else "false",
+        """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_halo.hip: sgg_halo_launch picks (default build)."""
+        tile = "2,128,2,2" if n_out % 128 == 0 else ("2,64,2,2" if n_out % 64 == 0 else "4,32,4,1")
+        return "conv_halo3_kernel<%s,%s,%s,%s,%s,%s>" % (tile, "true" if self.conv_precision in (1, 2) else "false", "true",
                                                          "true" if n_in == 32 else "false", "true" if lnp else "false",
                                                          "true" if self.conv_precision in (1, 4) else "false")
 
