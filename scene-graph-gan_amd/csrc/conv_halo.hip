@@ -51,14 +51,15 @@ __device__ __forceinline__ int halo_sw(int ry, int rx) { return ((rx >> 2) & 1) 
 // LNP: LN prologue - src is the producing layer's pre-LayerNorm output, normalised + ELU'd while the patch is staged.
 // ONE: single-piece mode (precision 1 / 4): one 16-bit plane, one MFMA per product.
 template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH, bool LNP, bool ONE = false>
-__global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParams p) {
   constexpr int P = ONE ? 1 : 2;
   constexpr int WN = BN / WGN, TM = 2, TN = WN / 32;
-  static_assert(WGM * WGN == 4 && NB * 64 / WGM == 64 && WN % 32 == 0 && TN >= 1, "a wave owns one 8x8 block x WN columns");
+  constexpr int THREADS = 64 * WGM * WGN;       // four waves (two workgroups per CU) or two (four workgroups per CU, one patch buffer)
+  static_assert((WGM * WGN == 4 || WGM * WGN == 2) && NB * 64 / WGM == 64 && WN % 32 == 0 && TN >= 1, "a wave owns one 8x8 block x WN columns");
   constexpr int PLANEB = NB * HALO_BLKB;
   constexpr int ITEMS = NB * 400;                       // (block, patch pixel, 8-channel group)
-  constexpr int NPASS = (ITEMS + 255) / 256;
-  constexpr bool DB = (2 * P * PLANEB <= SGG_HALO_DB_MAX);        // two patch buffers: one barrier per chunk instead of two
+  constexpr int NPASS = (ITEMS + THREADS - 1) / THREADS;
+  constexpr bool DB = (2 * P * PLANEB <= SGG_HALO_DB_MAX) && THREADS == 256;        // two patch buffers: one barrier per chunk instead of two
   __shared__ __attribute__((aligned(16))) unsigned char lds[(DB ? 2 : 1) * P * PLANEB];
   __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 1024 : 4];      // gamma[0..511], beta at +512 (C <= 512: host check)
 
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
   int it_meta[NPASS];      // bits 0..19 LDS byte offset inside a plane, 20..23 border bits, 24..25 block, 28 valid
 #pragma unroll
   for (int j = 0; j < NPASS; ++j) {
-    const int it = tid + 256 * j;
+    const int it = tid + THREADS * j;
     const int blk = it / 400, r = it % 400;
     const int px = r >> 2, ch8 = r & 3;
     const int ry = px / 10, rx = px % 10;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(HaloParams p) {
                  (ch8 << 26) | ((it < ITEMS) << 28);
   }
   if constexpr (LNP) {
-    for (int c = tid; c < p.ln_nc; c += 256) {      // (ln_nc = C, or 32 for the space-to-depth view: its four chunks are the same channels)
+    for (int c = tid; c < p.ln_nc; c += THREADS) {      // (ln_nc = C, or 32 for the space-to-depth view: its four chunks are the same channels)
       lnp_s[c] = p.ln_gamma[c];
       lnp_s[512 + c] = p.ln_beta[c];
     }
@@ -517,6 +518,12 @@ int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, 
 
 // 64-column layers run on two-block workgroups (2 x 2 waves of 64 pixels x 32 columns, two patch buffers, prefetch); -DSGG_HALO_N64_NB2=0:
 // four-block ones (4 waves of 64 x 64, one buffer, no prefetch: 0.1 ms per step slower)
+// 32-column layers run on two-wave workgroups (two blocks, one 30 KB patch buffer, four workgroups per CU: four independent phases
+// instead of two hide each other's chunk boundaries and store drains); -DSGG_HALO_N32_W2=0: four-wave workgroups of four blocks
+// (0.1 ms per step slower)
+#ifndef SGG_HALO_N32_W2
+#define SGG_HALO_N32_W2 1
+#endif
 #ifndef SGG_HALO_N64_NB2
 #define SGG_HALO_N64_NB2 1
 #endif
@@ -529,28 +536,30 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
   do {                                                                                                       \
     const int mtiles = sgg_cdiv(p.nblk, NB), ntn = p.N / BN;                                                 \
     int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       /* (tile, n-tile) pairs an XCD owns */                    \
-    int gx = per_xcd < 64 ? per_xcd : 64;           /* two resident workgroups on each of its 32 CUs */       \
+    const int cap = 32 * 8 / (WGM * WGN);           /* eight resident waves on each of its 32 CUs */            \
+    int gx = per_xcd < cap ? per_xcd : cap;                                                                  \
     gx = sgg_cdiv(gx, ntn) * ntn;                                                                            \
     p.gx = gx;                                                                                               \
     const dim3 grid((unsigned)(8 * gx));                                                                     \
     if (one) {                                                                                                                          \
-      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false, true>), grid, dim3(256), 0, st, p);   \
-      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false, true>), grid, dim3(256), 0, st, p);      \
-      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false, true>), grid, dim3(256), 0, st, p); \
-      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false, true>), grid, dim3(256), 0, st, p);               \
+      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);   \
+      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);      \
+      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p); \
+      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);               \
     } else if (p.ln_stats) {                                                                                                            \
-      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, true>), grid, dim3(256), 0, st, p);   \
-      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, true>), grid, dim3(256), 0, st, p);      \
-      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, true>), grid, dim3(256), 0, st, p); \
-      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, true>), grid, dim3(256), 0, st, p);               \
-    } else if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false>), grid, dim3(256), 0, st, p); \
-    else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false>), grid, dim3(256), 0, st, p);       \
-    else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false>), grid, dim3(256), 0, st, p);  \
-    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false>), grid, dim3(256), 0, st, p);                \
+      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, true>), grid, dim3(64 * WGM * WGN), 0, st, p);   \
+      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);      \
+      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, true>), grid, dim3(64 * WGM * WGN), 0, st, p); \
+      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);               \
+    } else if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false>), grid, dim3(64 * WGM * WGN), 0, st, p); \
+    else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false>), grid, dim3(64 * WGM * WGN), 0, st, p);       \
+    else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false>), grid, dim3(64 * WGM * WGN), 0, st, p);  \
+    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false>), grid, dim3(64 * WGM * WGN), 0, st, p);                \
   } while (0)
   if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true);
   else if (p.N % 64 == 0 && SGG_HALO_N64_NB2) SGG_HALO(2, 64, 2, 2, true);
   else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false);      // (with PREFETCH: 35 spilled VGPRs at the 256-register budget of two waves per SIMD)
+  else if (SGG_HALO_N32_W2) SGG_HALO(2, 32, 2, 1, true);
   else SGG_HALO(4, 32, 4, 1, true);
 #undef SGG_HALO
 }
