@@ -34,7 +34,10 @@ int sgg_hwio_to_hwoi(const float* w_hwio, float* w_hwoi, int taps, int cin, int 
 /* precision: 0 = native f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32);
  *            2 = f32 operands scaled by a per-tensor power of two (from amax_* = device words holding max|tensor|, see
  *                sgg_absmax / the amax_out of the LayerNorm kernels) and split into two fp16 pieces, 3 fp16 MFMAs, f32
- *                accumulate: 22 significant bits per operand, error vs fp64 equal to native f32;
+ *                accumulate: the two pieces are taken with round-to-nearest-even (v_cvt_pk_f16_f32; csrc/sgg_common.h f16_split2),
+ *                i.e. 23 significant bits per operand for elements within 2^-16 of the tensor maximum, min(23, 39 - d) bits for an
+ *                element 2^-d below it (DESIGN.md "Error model and its floor"); error vs fp64 within 2x native f32 + 3e-7 on every
+ *                configs[1] layer (tests/test_fullsize_conv_gpu.py);
  *            3 / 6 = split into 2 / 3 bf16 pieces, 3 / 6 bf16 MFMAs (6: f32-equivalent, 3: 2^-17 cross terms dropped);
  *            1 / 4 = MIXED PRECISION (not the reference's arithmetic): operands rounded to ONE fp16 (scaled
  *                like precision 2) / ONE bf16 piece, one MFMA per product, f32 accumulate - error vs fp64 2e-3 / 1.5e-2 of the

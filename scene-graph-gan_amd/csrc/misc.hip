@@ -11,7 +11,7 @@
 
 // ---- error / info (host) ----------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
-extern "C" void sgg_set_error(const char* fmt, ...) {
+extern "C" __attribute__((visibility("hidden"))) void sgg_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);

@@ -9,7 +9,8 @@
 #define SGG_ERR_LAUNCH (-2)
 #define SGG_ERR_WORKSPACE (-3)
 
-extern "C" void sgg_set_error(const char* fmt, ...);
+// library-internal (not part of the C ABI of include/sgg_hip.h: hidden, so that the exported sgg_* set equals the declared one)
+extern "C" __attribute__((visibility("hidden"))) void sgg_set_error(const char* fmt, ...);
 
 #define SGG_CHECK_ARG(cond, ...)                 \
   do {                                           \

@@ -35,7 +35,8 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 // 8 consecutive floats -> P planes of 8 sixteen-bit pieces (16 B each), x*scale = x0 + x1 (+ x2).
 //   HALF = false: bf16 pieces (RNE), scale unused.   HALF = true: fp16 pieces (P = 2) of the pre-scaled value; the scale
 //   is a power of two chosen from the tensor's max|x| so that |x*scale| <= 2^14 (no overflow, and the second piece
-//   only reaches fp16 subnormals 38 binades below the tensor's maximum): 22 significant bits in two pieces.
+//   only reaches fp16 subnormals 17 binades below the tensor's maximum): both pieces round to nearest even (f16_split2), so an
+//   element within 2^-16 of the maximum keeps 23 significant bits, one 2^-d below it min(23, 39 - d).
 template <int P, bool HALF>
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float scale, u32x4 (&pl)[P]) {
   float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};

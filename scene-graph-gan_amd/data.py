@@ -68,6 +68,50 @@ def _parse_task(task):
     return parse_image(path, means, stds, side)
 
 
+class ShuffledStream:
+    """Example indices in the order of the reference's training / validation datasets (train.py:176-179):
+
+        Dataset.from_tensor_slices(files, labels).repeat().shuffle(buffer_size = 10 * batch_size)
+
+    i.e. the (once-shuffled, train.py:130) file list walked cyclically for ever, passed through tf.data's rolling shuffle buffer:
+    the buffer is filled with the first `buffer` elements of the stream; every draw takes a uniformly random slot of the buffer and
+    refills that slot with the stream's next element.  An element therefore never appears earlier than `buffer - 1` positions
+    before its place in the cyclic walk, and every element of the walk is emitted exactly once.  TF's own random stream is not
+    reproducible outside TF: `seed` selects a NumPy one, fixed per (seed, stream), so a run and its resumed continuation see
+    the same order (`batch(it, ...)` is a pure function of `it`)."""
+
+    def __init__(self, n, buffer, seed=0):
+        assert n > 0 and buffer > 0
+        self.n, self.buffer, self.seed = int(n), int(buffer), seed
+        self._reset()
+
+    def _reset(self):
+        self.rng = np.random.RandomState(self.seed)
+        self.buf = [i % self.n for i in range(self.buffer)]
+        self.next_in = self.buffer
+        self.emitted = 0
+
+    def draw(self):
+        j = int(self.rng.randint(len(self.buf)))
+        out = self.buf[j]
+        self.buf[j] = self.next_in % self.n
+        self.next_in += 1
+        self.emitted += 1
+        return out
+
+    def take(self, start, count):
+        """Elements [start, start + count) of the shuffled stream (rewinds and replays when `start` lies behind the cursor)."""
+        if start < self.emitted:
+            self._reset()
+        while self.emitted < start:
+            self.draw()
+        return [self.draw() for _ in range(count)]
+
+    def batch(self, it, batch_size, rank=0, world=1):
+        """Global batch `it` is elements [it * B * world, (it + 1) * B * world) of the stream; rank r takes rows [r * B, (r + 1) * B)."""
+        return self.take(it * world * batch_size, world * batch_size)[rank * batch_size:(rank + 1) * batch_size]
+
+
 class PrefetchLoader:
     """Batches of (images [B, side, side, 3] float32, labels [B, 3] int64) on `device`, produced ahead of the consumer.
 
@@ -109,8 +153,55 @@ class PrefetchLoader:
         self.ready = queue.Queue(maxsize=depth)
         self.copy_stream = torch.cuda.Stream(device=self.device) if pin else None
         self.error = None
+        self._stop = threading.Event()
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.thread.start()
+
+    def _get_free(self):
+        while not self._stop.is_set():
+            try:
+                return self.free.get(timeout=0.1)
+            except queue.Empty:
+                continue
+        return None
+
+    def _put_ready(self, item):
+        while not self._stop.is_set():
+            try:
+                self.ready.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def close(self):
+        """Stop the producer (training ended early, or an exception in the consumer): set the stop flag, drain the queue the
+        producer may be blocked on, join it and release the decode pool.  Idempotent."""
+        self._stop.set()
+        try:
+            while True:
+                self.ready.get_nowait()
+        except queue.Empty:
+            pass
+        if self.thread.is_alive() and threading.current_thread() is not self.thread:
+            self.thread.join(timeout=30.0)
+        try:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+        except TypeError:                   # (cancel_futures: Python >= 3.9)
+            self.pool.shutdown(wait=False)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _fill(self, dst, j, path):
         dst[j] = torch.from_numpy(parse_image(path, self.means, self.stds, self.side))
@@ -119,9 +210,12 @@ class PrefetchLoader:
         try:
             for it in range(self.start, self.stop):
                 idx = self.index_fn(it)
-                slot = self.free.get()
+                slot = self._get_free()
+                if slot is None:
+                    return
                 if self.K is not None:
-                    self.ready.put(self._produce_device(slot, idx))
+                    if not self._put_ready(self._produce_device(slot, idx)):
+                        return
                     continue
                 buf = self.host[slot]
                 if self.processes:
@@ -140,11 +234,12 @@ class PrefetchLoader:
                         done.record(self.copy_stream)
                 else:
                     dev_images, dev_labels, done = buf.clone(), labels, None
-                self.ready.put((slot, dev_images, dev_labels, done))
+                if not self._put_ready((slot, dev_images, dev_labels, done)):
+                    return
         except BaseException as e:        # surfaced to the consumer: a failed decode must not look like end-of-data
             self.error = e
         finally:
-            self.ready.put(None)
+            self._put_ready(None)         # (gives up when close() was called: nobody is waiting then)
 
     def _produce_device(self, slot, idx):
         """Decode on worker threads, pack, one host-to-device copy, one resize + standardise launch (copy stream)."""
@@ -182,6 +277,8 @@ class PrefetchLoader:
         return self
 
     def __next__(self):
+        if self._stop.is_set():
+            raise StopIteration
         item = self.ready.get()
         if item is None:
             self.pool.shutdown(wait=False)

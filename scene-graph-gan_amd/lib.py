@@ -142,15 +142,17 @@ class HipKernels:
         self.timing_conv_only = False   # True: only the MFMA-bound convolution calls are bracketed (the timed region of bench.py)
         self.timing_symbols = None      # with timing_conv_only True: bracket only these kernel symbols (bench.py: the dominant one)
         # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
-        #   2 (default) f32 operands scaled by a per-tensor power of two and split into two fp16 pieces (22 significant
-        #               bits), 3 fp16 MFMAs per product, f32 accumulate: error against fp64 equal to the native f32 path's;
+        #   2 (default) f32 operands scaled by a per-tensor power of two and split into two fp16 pieces with round-to-nearest
+        #               (23 significant bits), 3 fp16 MFMAs per product, f32 accumulate: error against fp64 within 2x the native
+        #               f32 path's + 3e-7 (tests/test_fullsize_conv_gpu.py);
         #   6           three bf16 pieces, 6 bf16 MFMAs (no scaling needed): also f32-equivalent, slower;
         #   0           native f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 fmaf chain);
         #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance).
         self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
         self.conv_halo = os.environ.get("SGG_CONV_HALO", "1") != "0"
-        # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = in the forward-only
-        # encoder passes, for consumers on the 128-column halo kernel (-0.43 ms per step); 2 = wherever the kernels allow (slower:
+        # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = per layer and per KIND of
+        # encoder pass (forward-only / followed by a backward) where trunk.ln_fusion_pays' measured cost model says it pays
+        # (trunk._plan_ln_fusion: 28 of the 44 apply passes of a step at configs[1]); 2 = wherever the kernels allow (slower:
         # DESIGN.md); 0 = never
         self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "1"))
         self.ln_fusion_skip = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_SKIP", "").split(",") if v)   # A/B: conv indices

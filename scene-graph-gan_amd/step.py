@@ -113,13 +113,19 @@ class GanStep:
         call; only the recurrent head (fresh noise) is re-run.  bench.py never does this (every update recomputes everything)."""
         G = self.G
         if self._g_reuse is not None and self._g_reuse[0] is images:
+            # the kept encoder output is only valid for the tensor's contents at the first call: an in-place write to the minibatch
+            # (augmentation, a loader refilling its device buffer) or an optimiser step of G since then would silently train on stale
+            # activations.  (Invariant of the schedule: no G.head.backward runs between the first generator_forward of an iteration
+            # and generator_step, so the dP / dctx accumulators head.precompute cleared are still zero there.)
+            assert self._g_reuse[2] == (images.data_ptr(), images._version, G.adam_t), \
+                "G-encoder reuse: the minibatch tensor was modified in place (or G was updated) inside one iteration"
             ctx = self._g_reuse[1]
         else:
             keep = for_backward or self._g_reuse_armed
             ctx = G.trunk.forward(images, keep) if keep is False else G.trunk.forward(images)
             G.head.precompute(ctx)
             if self._g_reuse_armed:
-                self._g_reuse = (images, ctx)
+                self._g_reuse = (images, ctx, (images.data_ptr(), images._version, G.adam_t))
         st = G.head.state(1, self.B)
         G.head.forward(st, ctx, noise)
         return st, ctx
@@ -196,6 +202,37 @@ class GanStep:
         D.trunk.backward(dctx)
         D.update(self.reducer)
         return self.d_losses
+
+    def critic_loss(self, images, labels, noise, alpha, out=None):
+        """disc_cost of a minibatch WITHOUT an update: what `sess.run(self.disc_cost, feed_dict = {handle: val_handle})` evaluates
+        for the validation-loss early stop (train.py:375-377).  Same forward as critic_step; the head backward runs only as far as
+        g = d sum(D(x_hat)) / d x_hat needs it (no parameter gradient is touched, R_w = 0), no encoder backward, no Adam.
+        Returns (disc_cost, wasserstein term, gradient penalty, mean D(fake)) in `out` (default: a buffer of its own)."""
+        K, B, V, D = self.K, self.B, self.V, self.D
+        assert self._g_reuse is None and not self._g_reuse_armed, "critic_loss inside an iteration with G-encoder reuse"
+        if out is None:
+            if getattr(self, "val_losses", None) is None:
+                self.val_losses = torch.zeros_like(self.d_losses)
+            out = self.val_losses
+        fake_rows, real_rows, hat_rows = self.TRI[:B], self.TRI[B:2 * B], self.TRI[2 * B:]
+        self.flush()
+        ctx = D.trunk.forward(images, False)
+        D.head.precompute(ctx)
+        gst, _ = self.generator_forward(images, noise, for_backward=False)
+        fake_rows.copy_(gst.OUT[0])
+        K.onehot(labels, real_rows)
+        K.interpolate(real_rows, fake_rows, alpha, hat_rows)
+        st = D.head.state(1, 3 * B)
+        D.head.forward(st, ctx, [self.TRI], labels, (B, 2 * B))
+        K.fill(st.dOUT[0][:2 * B], 0.0)
+        K.fill(st.dOUT[0][2 * B:], 1.0)           # d sum(D(x_hat)) -> g
+        D.head.backward(st, ctx, [self.TRI], R_w=0)
+        ind = D.head.in_dim
+        for t in range(T_STEPS):
+            K.gemm_nt(st.dXH[t][0][2 * B:, FEAT_C:ind], D.head.W_emb, self.gbuf[:, t, :])
+        K.gp_fwd(self.gbuf, self.slopes, self.pen)
+        K.wgan_losses(st.OUT[0].view(3 * B, T_STEPS), self.pen, self.lam, B, T_STEPS, True, out)
+        return out
 
     def generator_step(self, images, noise):
         """One gen_train_op (train.py:368). Returns self.g_losses; g_losses[3] = mean D(fake) = -gen_cost."""

@@ -108,5 +108,15 @@ def test_real_data_pipeline_and_evaluation(tmp_path):
         next(loader)
     gan.train(max_iterations=1)
     assert torch.isfinite(gan.step.d_losses).all() and os.path.exists(gan._ckpt_path())
-    r50, r100 = gan.test(max_images=1, out_path=str(tmp_path / "recalls.txt"))
-    assert 0.0 <= r50 <= 1.0 and 0.0 <= r100 <= 1.0 and os.path.exists(str(tmp_path / "recalls.txt"))
+    # evaluation on the test split of the real-data files, against the oracle's restatement of train.py:297-335 on the same
+    # weights, decoded images and noise (tests/test_f1_f3_gpu.py does the same at 128 samples per image)
+    from oracle import eval_ref as ER
+    (r50, r100), details = gan.test(max_images=1, out_path=str(tmp_path / "recalls.txt"), return_details=True)
+    key, triples = gan.test_items[0]
+    gen = torch.Generator().manual_seed(gan.seed + 123)
+    n_samples = gan.TEST_BATCH_MULTIPLIER * gan.TEST_BATCH_SIZE
+    noises = [torch.randn((4, 512), generator=gen) for _ in range(-(-n_samples // 4))]
+    exp = ER.evaluate_image(gan.g.state_dict(full_names=False), gan.d.state_dict(full_names=False), gan._parseFunction(key), triples, noises)
+    assert np.array_equal(details[0]["tokens"], exp["tokens"][:n_samples])
+    assert float(np.abs(details[0]["scores"] - exp["scores"][:n_samples]).max()) <= 1e-4 + 1e-4 * float(np.abs(exp["scores"]).max())
+    assert (r50, r100) == (exp["r50"], exp["r100"]) and os.path.exists(str(tmp_path / "recalls.txt"))

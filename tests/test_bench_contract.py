@@ -57,3 +57,29 @@ def test_cli_contract_flags_exist():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--critic-iters", "--cpu-rows", "--f32-steps"):
         assert flag in out.stdout
+
+
+def test_gpus_n_starts_its_own_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher on the command line and no WORLD_SIZE in the environment (the form the driver
+    may use): bench.py starts `python -m torch.distributed.run` as a child, the two ranks meet over gloo (SGG_DP_BACKEND; "nccl" =
+    RCCL on a GPU node), all-reduce a bucket through sgg_amd.dp.GradReducer, and the parent relays rank 0's ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SGG_DP_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl"]["nranks"] == 2 and rec["rccl"]["backend"] == "gloo" and rec["rccl"]["allreduce_mean_ok"]
+
+
+def test_self_launch_relays_the_exit_code_of_the_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SGG_DP_BACKEND"] = "gloo"
+    # without --rendezvous-only the ranks need MI355X GPUs: on a CPU box they must fail loudly (no CPU fallback), and so must the parent
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                          "--size", "32", "--vocab", "11", "--cpu-rows", "0"], capture_output=True, text=True, timeout=600, env=env)
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import sgg_amd  # noqa: F401
 from sgg_amd import build, lib
@@ -24,6 +25,10 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(dll, n), "libsgg_hip.so does not export %s" % n
     assert set(names) == set(lib.SIGNATURES), set(names) ^ set(lib.SIGNATURES)
+    # exported == declared: nothing else with the library's prefix leaks out of the shared object (helpers are hidden)
+    nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in nm.splitlines() if l.split() and l.split()[-1].startswith("sgg_")})
+    assert exported == names, set(exported) ^ set(names)
     loaded = lib.load_library(path)
     assert loaded.sgg_version() == 100
 

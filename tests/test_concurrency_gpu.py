@@ -109,3 +109,63 @@ def test_two_stream_schedule_is_bitwise_the_serial_one(hip, ln_fusion):
             assert not bad, "repetition %d: %d tensors differ, first %s" % (rep, len(bad), bad[:3])
     finally:
         hip.ln_fusion = old_fusion
+
+
+def test_step_is_unchanged_beside_collective_like_traffic(hip):
+    """Data parallel runs RCCL's all-reduce kernels on their own stream beside EVERY kernel of the step (sgg_amd/dp.py: the critic's
+    reduce under G's forward, the generator's under D's encoder).  A ring all-reduce is, per hop, a copy of a bucket chunk and a
+    reduction (add) into the bucket, repeated; RCCL itself needs a second GPU, so its stand-ins here are large `copy_` / `add_`
+    launches over 64 MB buckets (the GradReducer bucket size) looping on a second stream for the whole critic + generator step:
+    HBM-saturating vector kernels beside the MFMA kernels - the other side of the packed-fp32 finding above.  Every output, every
+    gradient and every weight must equal the serial step's bit for bit."""
+    img, lab, noise0, noise1, alpha = _inputs()
+    side = torch.cuda.Stream()
+    n = (64 << 20) // 4
+    bucket, recv = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    bucket2 = torch.zeros(n, device="cuda")
+
+    def ring(hops):
+        # (whole 64 MB buckets per launch: ~25 us of HBM-saturating traffic each, so the GPU side outlasts the host's enqueue of the step)
+        for h in range(hops):
+            recv.copy_(bucket)                 # "receive" the neighbour's bucket
+            bucket2.add_(recv)                 # reduce it into the local one
+            bucket.copy_(bucket2)              # forward the partial sum
+        bucket2.mul_(1.0 / 8.0)
+
+    def run(beside):
+        gs = _new_step(hip)
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            beside()
+        gs.critic_step(img, lab, noise0, alpha)
+        gs.generator_step(img, noise1)
+        gs.flush()
+        overlapped = not side.query()
+        return _snapshot(gs), overlapped
+
+    ref, _ = run(lambda: None)
+    for rep in range(4):
+        got, overlapped = run(lambda: ring(1500))
+        assert overlapped, "the collective-like traffic finished before the step was enqueued: nothing was tested"
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, "beside ring-all-reduce-like traffic (repetition %d) %d tensors differ, first %s" % (rep, len(bad), bad[:3])
+    # and on the two-stream schedule (three streams busy)
+    gs_ref = _new_step(hip, overlap_streams=True)
+    gs_ref.critic_step(img, lab, noise0, alpha)
+    gs_ref.generator_step(img, noise1)
+    gs_ref.flush()
+    ref2 = _snapshot(gs_ref)
+    gs = _new_step(hip, overlap_streams=True)
+    torch.cuda.synchronize()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ring(1500)
+    gs.critic_step(img, lab, noise0, alpha)
+    gs.generator_step(img, noise1)
+    gs.flush()
+    assert not side.query()
+    got2 = _snapshot(gs)
+    bad = [k for k in ref2 if not torch.equal(ref2[k], got2[k])]
+    assert not bad, "two-stream schedule beside ring-like traffic: %d tensors differ, first %s" % (len(bad), bad[:3])
+    assert all(torch.equal(ref[k], ref2[k]) for k in ref)

@@ -13,24 +13,8 @@ import pytest
 import torch
 
 import sgg_amd  # noqa: F401
+from oracle.data_ref import early_stop_ref, resize_loop, shuffled_stream_ref
 from sgg_amd import data as D
-
-
-def resize_loop(img, oh, ow):
-    """tf.image.resize_images(img, [oh, ow]) of TF 1.x, one output pixel at a time."""
-    H, W, C = img.shape
-    out = np.zeros((oh, ow, C), dtype=np.float32)
-    sy, sx = np.float32(H) / np.float32(oh), np.float32(W) / np.float32(ow)
-    for y in range(oh):
-        fy = np.float32(y) * sy
-        y0 = int(np.floor(fy)); y1 = min(y0 + 1, H - 1); wy = np.float32(fy - y0)
-        for x in range(ow):
-            fx = np.float32(x) * sx
-            x0 = int(np.floor(fx)); x1 = min(x0 + 1, W - 1); wx = np.float32(fx - x0)
-            top = img[y0, x0] + (img[y0, x1] - img[y0, x0]) * wx
-            bot = img[y1, x0] + (img[y1, x1] - img[y1, x0]) * wx
-            out[y, x] = top + (bot - top) * wy
-    return out
 
 
 @pytest.mark.parametrize("shape,out", [((37, 53), (21, 21)), ((13, 9), (21, 17)), ((50, 75), (22, 22)), ((5, 5), (5, 5)), ((1, 7), (3, 3))])
@@ -178,3 +162,95 @@ def test_canvas_plan_for_odd_image_sizes():
     assert plan_canvas(37) is None                                                 # canvas 48: 1.68x the pixels
     p29 = plan_canvas(29)
     assert p29[0][:3] == (32, 3, 29) and p29[2][3:] == (16, 1, 15) and p29[7][3:] == (8, 0, 8)
+
+
+def test_shuffled_stream_is_tf_data_repeat_shuffle():
+    """train.py:176-179: repeat().shuffle(10 * batch) - sgg_amd.data.ShuffledStream against the element-by-element restatement fed
+    with the same slot numbers, plus the properties any such buffer has."""
+    n, buf, seed = 37, 12, 5
+    st = D.ShuffledStream(n, buf, seed)
+    got = st.take(0, 400)
+    rng = np.random.RandomState(seed)                                               # the stream draws one slot per output
+    slots = [int(rng.randint(buf)) for _ in range(400)]
+    assert got == shuffled_stream_ref(n, buf, slots)
+    # (a) a pure function of the position: replays, resumes and out-of-order requests agree
+    assert D.ShuffledStream(n, buf, seed).take(100, 50) == got[100:150]
+    assert st.take(30, 10) == got[30:40] and st.take(390, 10) == got[390:400]
+    # (b) an element never appears earlier than buffer - 1 positions before its place in the cyclic walk, and nothing is lost or
+    # duplicated: after k outputs exactly the first k + buffer inputs minus the buffer's current content have been emitted
+    walk_pos = {}
+    for pos, e in enumerate(got):
+        k = walk_pos.get(e, -1) + 1
+        # occurrence number k of element e sits at input position e + k * n
+        assert pos >= e + k * n - (buf - 1), (pos, e, k)
+        walk_pos[e] = k
+    counts = np.bincount(got, minlength=n)
+    assert counts.max() - counts.min() <= 1 + buf // n + 1
+    # (c) data parallel: the ranks' rows are disjoint slices of one global batch
+    a, b = D.ShuffledStream(n, buf, seed), D.ShuffledStream(n, buf, seed)
+    g = D.ShuffledStream(n, buf, seed).take(3 * 8, 8)
+    assert a.batch(3, 4, 0, 2) == g[:4] and b.batch(3, 4, 1, 2) == g[4:]
+    # a buffer of 1 is the plain cyclic walk
+    assert D.ShuffledStream(5, 1, 0).take(0, 12) == [i % 5 for i in range(12)]
+
+
+def test_validation_early_stop_matches_reference_loop():
+    from train import ValidationEarlyStop, _str2bool
+    cases = [[5, 4, 3, 2], [1, 2, 3, 4], [3, 4, 5, 4, 5, 6, 7], [1, 1, 1, 1, 1], [2, 3, 4, 1, 2, 3, 4, 5], [float("inf"), 1, 2, 3, 4],
+             [1, 2, 3, 2.5, 3, 4, 5]]
+    for losses in cases:
+        es, got = ValidationEarlyStop(3), None
+        for i, l in enumerate(losses):
+            if es.update(l):
+                got = i
+                break
+        assert got == early_stop_ref(losses, 3), losses
+    assert early_stop_ref([1, 2, 3, 4]) == 3 and early_stop_ref([3, 4, 5, 4, 5, 6, 7]) == 6 and early_stop_ref([1, 1, 1, 1]) is None
+    # --resume False must be false (the reference's type=bool makes it true, train.py:410)
+    assert _str2bool("False") is False and _str2bool("0") is False and _str2bool("true") is True and _str2bool(True) is True
+    with pytest.raises(Exception):
+        _str2bool("maybe")
+
+
+def test_recall_oracle_agrees_with_product_ranking():
+    """oracle/eval_ref.py restates train.py:317-326 on NumPy arrays exactly as written; train.SceneGraphGAN.recalls must give the same
+    numbers in both ordering modes on the same (tokens, scores, real) - here without any network: the accumulators are inputs."""
+    from oracle import eval_ref as E
+    ev = _Eval()
+    rng = np.random.RandomState(3)
+    fake = rng.randint(0, 6, size=(128, 3))                     # few distinct triples: the set semantics matter
+    scores = rng.randn(128).astype(np.float32)
+    scores[10] = scores[20]                                     # a tie
+    real = [fake[5].tolist(), fake[77].tolist(), [9, 9, 9]]
+    for literal in (False, True):
+        score_acc = scores.astype(np.float64).reshape(-1, 1)
+        fake_acc = fake.astype(np.float64)
+        if literal:
+            idx = score_acc.argsort()
+            s50, s100 = np.squeeze(fake_acc[idx[:50]], axis=1), np.squeeze(fake_acc[idx[:100]], axis=1)
+        else:
+            idx = score_acc.reshape(-1).argsort(kind="stable")
+            s50, s100 = fake_acc[idx[:50]], fake_acc[idx[:100]]
+        exp = (E.recall(s50, np.asarray(real, np.float64), 50.0), E.recall(s100, np.asarray(real, np.float64), 100.0))
+        assert ev.recalls(fake, scores, real, reference_literal=literal) == exp
+
+
+def test_prefetch_loader_close_releases_a_blocked_producer(tmp_path):
+    """Training that stops early (exception, early stop, max_iterations below the loader's stop) must not leave the producer thread
+    blocked on its bounded queue holding buffers: close() stops it; iterating afterwards ends."""
+    files = _write_jpegs(tmp_path, 6)
+    loader = D.PrefetchLoader(files, np.zeros((6, 3), np.int64), 2, lambda it: [(2 * it + j) % 6 for j in range(2)], [0, 0, 0], [1, 1, 1], "cpu",
+                              1000, workers=2, side=9)
+    first = next(loader)
+    assert first[0].shape == (2, 9, 9, 3)
+    import time
+    time.sleep(0.3)                         # the producer now sits in a full `ready` queue / an empty `free` queue
+    assert loader.thread.is_alive()
+    loader.close()
+    assert not loader.thread.is_alive()
+    with pytest.raises(StopIteration):
+        next(loader)
+    loader.close()                          # idempotent
+    with D.PrefetchLoader(files, np.zeros((6, 3), np.int64), 2, lambda it: [0, 1], [0, 0, 0], [1, 1, 1], "cpu", 50, workers=2, side=9) as l2:
+        next(l2)
+    assert not l2.thread.is_alive()

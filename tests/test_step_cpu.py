@@ -123,3 +123,46 @@ def test_generator_encoder_reuse_within_iteration_is_exact():
     for a, b in zip(res[False], res[True]):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_critic_loss_without_update_matches_oracle_and_half_batch():
+    """GanStep.critic_loss = the validation loss of train.py:375-377 (`sess.run(self.disc_cost, ...)` on a validation batch): the
+    oracle's d_loss on the same inputs, no weight / gradient / Adam state touched; and the value on a VAL_BATCH_SIZE = B / 2 batch
+    (train.py:30) is what the B-row machinery returns on that batch repeated twice (every term is a mean over rows)."""
+    B, S, V = 4, 32, 11
+    gp, dp = make_states(V, S)
+    gs = GanStep(RefKernels(), V, S, B, lam=10.0, g_state=gp, d_state=dp, dtype=DT)
+    images, labels, onehot = O.synth_batch(B, S, V, dtype=DT)
+    noise, alpha = O.synth_noise(B, 0, DT), O.synth_alpha(B, 0, DT)
+    w0 = [gs.G.arena.flat.clone(), gs.D.arena.flat.clone(), gs.D.grad_flat.clone(), gs.D.m_flat.clone()]
+    got = gs.critic_loss(images, labels, noise, alpha.reshape(B)).clone()
+    cost, aux = O.d_loss(gp, dp, images, onehot, noise, alpha, 10.0)
+    assert float(aux["gp"]) > 1e-3
+    assert abs(float(got[0]) - float(cost)) < 1e-9 and abs(float(got[2]) - float(aux["gp"])) < 1e-9
+    assert abs(float(got[1]) - float(aux["wdist"])) < 1e-9
+    for a, b in zip(w0, [gs.G.arena.flat, gs.D.arena.flat, gs.D.grad_flat, gs.D.m_flat]):
+        assert torch.equal(a, b)
+    assert gs.D.adam_t == 0 and gs.G.adam_t == 0
+    # half batch repeated twice == the half batch's own loss
+    h = B // 2
+    rep = lambda t: torch.cat([t[:h], t[:h]])
+    got2 = gs.critic_loss(rep(images), rep(labels), rep(noise), rep(alpha.reshape(B))).clone()
+    cost_h, aux_h = O.d_loss(gp, dp, images[:h], onehot[:h], noise[:h], alpha[:h], 10.0)
+    assert abs(float(got2[0]) - float(cost_h)) < 1e-9
+    # a training step afterwards is unaffected by the evaluation in between
+    gs.critic_step(images, labels, noise, alpha.reshape(B))
+    gs2 = GanStep(RefKernels(), V, S, B, lam=10.0, g_state=gp, d_state=dp, dtype=DT)
+    gs2.critic_step(images, labels, noise, alpha.reshape(B))
+    assert torch.equal(gs.D.arena.flat, gs2.D.arena.flat)
+
+
+def test_generator_encoder_reuse_rejects_a_modified_minibatch():
+    B, S, V = 2, 32, 11
+    gp, dp = make_states(V, S)
+    gs = GanStep(RefKernels(), V, S, B, lam=10.0, g_state=gp, d_state=dp, dtype=DT)
+    images, labels, _ = O.synth_batch(B, S, V, dtype=DT)
+    with pytest.raises(AssertionError, match="modified in place"):
+        with gs.iteration(reuse_g_encoder=True):
+            gs.critic_step(images, labels, O.synth_noise(B, 0, DT), O.synth_alpha(B, 0, DT).reshape(B))
+            images.mul_(1.5)                     # an augmentation / a loader refilling its buffer between two updates
+            gs.critic_step(images, labels, O.synth_noise(B, 1, DT), O.synth_alpha(B, 1, DT).reshape(B))

@@ -27,9 +27,25 @@ from architectures.discriminator_with_attention import Discriminator
 import sgg_amd  # noqa: F401
 from sgg_amd import dp as dpmod
 from sgg_amd.api import kernels_for
-from sgg_amd.data import PrefetchLoader, parse_image
+from sgg_amd.data import PrefetchLoader, ShuffledStream, parse_image
 from sgg_amd.params import EMBED_DIM
 from sgg_amd.step import GanStep
+
+
+class ValidationEarlyStop(object):
+    """The convergence test of train.py:358-384: `last_loss = inf; convergence_count = 0`, then per validation
+    `if last_loss < loss: count += 1 else: count = 0; if count == 3: break; last_loss = loss`."""
+
+    def __init__(self, patience=3):
+        self.patience, self.count, self.last = int(patience), 0, float("inf")
+
+    def update(self, loss):
+        """True = stop training now."""
+        self.count = self.count + 1 if self.last < loss else 0
+        if self.count == self.patience:
+            return True
+        self.last = loss
+        return False
 
 
 class SceneGraphGAN(object):
@@ -39,7 +55,7 @@ class SceneGraphGAN(object):
     ############################################################
     def __init__(self, checkpoints_dir, summaries_dir, path_to_ims_to_triples, path_to_vocab, path_to_word_embeddings,
                  path_to_image_means, path_to_image_stds, critic_iters, batch_size, lambda_, resume,
-                 synthetic=None, device=None, seed=0, two_streams=True, reuse_g_encoder=True):
+                 synthetic=None, device=None, seed=0, two_streams=True, reuse_g_encoder=True, shuffle_buffer=True):
         # Hyperparameters (train.py:26-32)
         self.CRITIC_ITERS = int(critic_iters)
         self.BATCH_SIZE = int(batch_size)
@@ -52,6 +68,7 @@ class SceneGraphGAN(object):
         # chain): same kernels, bit-identical results (tests/test_concurrency_gpu.py), +4 % triples/s
         self.two_streams = bool(two_streams)
         self.reuse_g_encoder = bool(reuse_g_encoder)
+        self.shuffle_buffer = bool(shuffle_buffer)      # tf.data shuffle(buffer_size = 10 * batch) on the repeated stream (train.py:176-179)
         self.checkpoints_dir, self.summaries_dir = checkpoints_dir, summaries_dir
         self.rank, self.world, local = dpmod.init_from_env()
         self.device = torch.device(device if device is not None else "cuda:%d" % local)
@@ -112,17 +129,41 @@ class SceneGraphGAN(object):
         perm = np.random.RandomState(self.seed).permutation(len(files))
         files, labels = [files[i] for i in perm], np.asarray(labels, dtype=np.int64)[perm]
         thr = int(0.88 * len(files))
-        self.max_iterations = 5 * thr
+        self.max_iterations = 5 * thr                                       # train.py:159
+        self.write_iterations = 10                                          # train.py:161
+        self.validate_iterations = max(1, int(thr / 50))                    # train.py:162
         return {"train": (files[:thr], labels[:thr]), "val": (files[thr:], labels[thr:])}
+
+    def _streams(self):
+        """The example order of the reference's datasets (train.py:176-179): the shuffled list repeated for ever, through a rolling
+        shuffle buffer of 10 batches (sgg_amd.data.ShuffledStream).  One stream per consumer (the prefetching loader's producer
+        thread, the synchronous path, validation): same seed -> same order."""
+        if getattr(self, "_stream_cache", None) is None:
+            B, VB = self.BATCH_SIZE, self._val_rows()
+            n_tr = len(self.dataset["train"][0]) if self.dataset is not None else 0
+            n_va = len(self.dataset["val"][0]) if self.dataset is not None else 0
+            mk = lambda n, b, salt: ShuffledStream(n, 10 * b * self.world, seed=self.seed + salt) if (n and self.shuffle_buffer) else None
+            self._stream_cache = {"loader": mk(n_tr, B, 11), "sync": mk(n_tr, B, 11), "val": mk(n_va, VB, 12)}
+        return self._stream_cache
+
+    def _val_rows(self):
+        """VAL_BATCH_SIZE = BATCH_SIZE / 2 (train.py:30).  The B-row step machinery evaluates it as that batch repeated twice (every loss
+        term is a mean over rows: same value); an odd BATCH_SIZE validates on BATCH_SIZE rows instead."""
+        B = self.BATCH_SIZE
+        return B // 2 if (B % 2 == 0 and B >= 2) else B
 
     def _parseFunction(self, filename):
         """JPEG decode -> tf.image.resize_images([221, 221]) (TF-1.x bilinear, align_corners=False, no antialiasing) ->
         (x - mean) / std (train.py:167-172), on the host: sgg_amd/data.py."""
         return torch.from_numpy(parse_image(filename, self.image_means.numpy(), self.image_stds.numpy()))
 
-    def _batch_indices(self, it):
-        """Example indices of iteration `it` on this rank (rank r takes rows [r*B, (r+1)*B) of the global batch)."""
+    def _batch_indices(self, it, stream="sync"):
+        """Example indices of iteration `it` on this rank (rank r takes rows [r*B, (r+1)*B) of the global batch): batch `it` of the
+        repeated + buffer-shuffled stream (train.py:176-179), or of the plain cyclic walk with shuffle_buffer=False."""
         B, n = self.BATCH_SIZE, len(self.dataset["train"][0])
+        st = self._streams()[stream]
+        if st is not None:
+            return st.batch(it, B, self.rank, self.world)
         return [(it * B * self.world + self.rank * B + j) % n for j in range(B)]
 
     def _next_batch(self, it):
@@ -138,12 +179,43 @@ class SceneGraphGAN(object):
             labels = torch.from_numpy(labs[idx])
         return images.to(self.device), labels.to(self.device)
 
+    def _val_batch(self, k):
+        """Validation batch k (the live validation iterator of train.py:199-203): VAL_BATCH_SIZE examples of the validation split in
+        its own repeated + shuffled order, laid out as BATCH_SIZE rows (see _val_rows)."""
+        B, VB = self.BATCH_SIZE, self._val_rows()
+        if self.dataset is None:
+            g = torch.Generator().manual_seed(self.seed + 5000 + 17 * k + 1000 * self.rank)
+            images = torch.randn((VB, self.image_size, self.image_size, 3), generator=g)
+            labels = torch.randint(0, len(self.vocab), (VB, 3), generator=g, dtype=torch.int64)
+        else:
+            files, labs = self.dataset["val"]
+            st = self._streams()["val"]
+            idx = st.batch(k, VB, self.rank, self.world) if st is not None else \
+                [(k * VB * self.world + self.rank * VB + j) % len(files) for j in range(VB)]
+            images = torch.stack([self._parseFunction(files[i]) for i in idx])
+            labels = torch.from_numpy(labs[idx])
+        rep = B // VB
+        return images.repeat(rep, 1, 1, 1).to(self.device), labels.repeat(rep, 1).to(self.device), rep
+
+    def validation_loss(self, k, gen):
+        """np.mean(sess.run(self.disc_cost, feed_dict = {handle: val_handle})) (train.py:377): the critic's cost on validation batch k with
+        fresh noise / alpha, no update; averaged over the data-parallel ranks so that every rank takes the same early-stop decision."""
+        images, labels, rep = self._val_batch(k)
+        VB = self._val_rows()
+        noise = torch.randn((VB, 512), generator=gen).repeat(rep, 1).to(self.device)
+        alpha = torch.rand((VB,), generator=gen).repeat(rep).to(self.device)
+        loss = self.step.critic_loss(images, labels, noise, alpha)[0:1].clone()
+        if self.world > 1:
+            torch.distributed.all_reduce(loss)
+            loss /= self.world
+        return float(loss.item())
+
     def _prefetcher(self, start, stop, workers=16):
         """tf.contrib.data.map_and_batch + prefetch (train.py:181-187) as decode threads + a pinned double buffer whose
         host-to-device copy runs on its own stream while the previous batch trains."""
         files, labs = self.dataset["train"]
-        return PrefetchLoader(files, labs, self.BATCH_SIZE, self._batch_indices, self.image_means.numpy(), self.image_stds.numpy(),
-                              self.device, stop, start=start, workers=workers, processes=workers > 2)
+        return PrefetchLoader(files, labs, self.BATCH_SIZE, lambda it: self._batch_indices(it, "loader"), self.image_means.numpy(),
+                              self.image_stds.numpy(), self.device, stop, start=start, workers=workers, processes=workers > 2)
 
     ############################################################
     ## Saving
@@ -177,37 +249,63 @@ class SceneGraphGAN(object):
         self.step = GanStep(kernels_for(self.device), V, S, B, lam=self.LAMBDA, G=g_net, D=d_net, reducer=reducer,
                             overlap_streams=self.two_streams)
 
-    def train(self, max_iterations=None, log_every=10, save_every=0):
+    def train(self, max_iterations=None, log_every=10, save_every=0, validate_every=None, test_at_end=None, patience=3):
+        """train.py:341-388.  Every `validate_every` iterations (default: the reference's len(train) / 50 on real data, off in
+        synthetic mode) the critic's cost on a validation batch is compared with the previous one: `patience` (3) consecutive
+        increases end the training (train.py:375-384); afterwards the model is evaluated (`print "Testing"; self.test(sess)`,
+        train.py:387-388) - by default on real data only."""
         images, labels = self._next_batch(0)
         self._constructOps(images)
         if self.resume and os.path.exists(self._ckpt_path()):
             self._loadModel()
         n_it = max_iterations if max_iterations is not None else getattr(self, "max_iterations", 1000)
+        if validate_every is None:
+            validate_every = getattr(self, "validate_iterations", 0) if self.dataset is not None else 0
+        if test_at_end is None:
+            test_at_end = self.dataset is not None
         gen = torch.Generator().manual_seed(self.seed + 7 + self.rank)
+        vgen = torch.Generator().manual_seed(self.seed + 70007 + self.rank)
         log = open(os.path.join(self.summaries_dir, "losses.jsonl"), "a") if self.rank == 0 else None
         B, t0, itr0 = self.BATCH_SIZE, time.time(), self.itr
         loader = self._prefetcher(self.itr, n_it) if self.dataset is not None else None
-        while self.itr < n_it:
-            images, labels = next(loader) if loader is not None else self._next_batch(self.itr)
-            # every update of an iteration sees the same minibatch (train.py:175-190) and G's weights change only at its end: G's
-            # encoder runs once per iteration (exact; 10 of 11 encoder forwards of G saved at CRITIC_ITERS = 10)
-            with self.step.iteration(reuse_g_encoder=self.reuse_g_encoder):
-                for _ in range(self.CRITIC_ITERS):                                  # train.py:364-365
+        stopper, self.stopped_early, self.val_history = ValidationEarlyStop(patience), False, []
+        try:
+            while self.itr < n_it:
+                images, labels = next(loader) if loader is not None else self._next_batch(self.itr)
+                # every update of an iteration sees the same minibatch (train.py:175-190) and G's weights change only at its end: G's
+                # encoder runs once per iteration (exact; 10 of 11 encoder forwards of G saved at CRITIC_ITERS = 10)
+                with self.step.iteration(reuse_g_encoder=self.reuse_g_encoder):
+                    for _ in range(self.CRITIC_ITERS):                                  # train.py:364-365
+                        noise = torch.randn((B, 512), generator=gen).to(self.device)
+                        alpha = torch.rand((B,), generator=gen).to(self.device)
+                        self.step.critic_step(images, labels, noise, alpha)
                     noise = torch.randn((B, 512), generator=gen).to(self.device)
-                    alpha = torch.rand((B,), generator=gen).to(self.device)
-                    self.step.critic_step(images, labels, noise, alpha)
-                noise = torch.randn((B, 512), generator=gen).to(self.device)
-                self.step.generator_step(images, noise)                             # train.py:368
-            self.itr += 1
-            if log is not None and self.itr % log_every == 0:
-                d, g = self.step.d_losses.cpu().tolist(), self.step.g_losses.cpu().tolist()
-                rate = B * self.world * (self.itr - itr0) / (time.time() - t0)      # of this run (a resumed run starts at itr0 > 0)
-                rec = {"itr": self.itr, "disc_loss": d[0], "gen_loss": -g[3], "gp": d[2], "triples_per_s": rate}
-                log.write(json.dumps(rec) + "\n"); log.flush()
-                print(rec)
-            if save_every and self.itr % save_every == 0:
-                self._saveModel()
+                    self.step.generator_step(images, noise)                             # train.py:368
+                itr = self.itr                                                          # the reference's 0-based loop variable
+                self.itr += 1
+                if log is not None and self.itr % log_every == 0:
+                    d, g = self.step.d_losses.cpu().tolist(), self.step.g_losses.cpu().tolist()
+                    rate = B * self.world * (self.itr - itr0) / (time.time() - t0)      # of this run (a resumed run starts at itr0 > 0)
+                    rec = {"itr": self.itr, "disc_loss": d[0], "gen_loss": -g[3], "gp": d[2], "triples_per_s": rate}
+                    log.write(json.dumps(rec) + "\n"); log.flush()
+                    print(rec)
+                if save_every and self.itr % save_every == 0:
+                    self._saveModel()
+                if validate_every and itr % validate_every == 0:                        # train.py:375-384
+                    loss = self.validation_loss(len(self.val_history), vgen)
+                    self.val_history.append((itr, loss))
+                    if log is not None:
+                        log.write(json.dumps({"itr": self.itr, "val_disc_loss": loss}) + "\n"); log.flush()
+                    if stopper.update(loss):
+                        self.stopped_early = True
+                        break
+        finally:
+            if loader is not None:
+                loader.close()
         self._saveModel()
+        if test_at_end:
+            print("Testing")                                                            # train.py:387-388
+            return self.test()
 
     ############################################################
     ## Testing (train.py:294-335)
@@ -233,11 +331,18 @@ class SceneGraphGAN(object):
         fake, real = np.asarray(fake), np.asarray(real, dtype=np.int64).reshape(-1, 3)
         return self._recall(fake[order[:50]], real, 50.0), self._recall(fake[order[:100]], real, 100.0)
 
-    def test(self, max_images=None, out_path="recalls.txt", reference_literal=False):
-        """R@50 / R@100 as the reference computes them: per test image, TEST_BATCH_MULTIPLIER x TEST_BATCH_SIZE
-        generator samples, scored by the mean critic output over the three steps, sorted ascending
-        (`score_accumulator.argsort()`, train.py:321), the first 50 / 100 compared as sets with the image's true
-        triples.  Uses the trained weights (the reference's test ops use an untrained copy)."""
+    def test(self, max_images=None, out_path="recalls.txt", reference_literal=False, items=None, return_details=False):
+        """R@50 / R@100 (train.py:297-335): per test image TEST_BATCH_MULTIPLIER x TEST_BATCH_SIZE generator samples, each scored by
+        the mean critic output over the three steps (`np.mean(disc_scores, axis=1)`, :315), ordered by score, the first 50 / 100
+        compared as sets with the image's true triples (:294-295, :325-326), averaged over the images, written to recalls.txt.
+
+        ORDERING.  Default (reference_literal=False): ascending mean critic score - what `score_accumulator.argsort()` (:321) is
+        written to mean.  This is NOT what the reference's code computes: its score array has shape [N, 1], so argsort sorts the
+        length-1 axis and every selected index is 0 (sample 0 repeated).  reference_literal=True reproduces
+        that literally.  The mode in force is written into recalls.txt (third line) and returned with the details.
+        Uses the trained weights (the reference's test ops use an untrained copy).
+        items: optional list of (image [S,S,3] float tensor, true triples [[s,p,o], ...]) replacing the test split.
+        return_details: also return, per image, the sampled tokens [N,3], their scores [N] and the two recalls."""
         if self.step is None:
             images, _ = self._next_batch(0)
             self._constructOps(images)
@@ -245,7 +350,9 @@ class SceneGraphGAN(object):
         B, K = self.BATCH_SIZE, kernels_for(self.device)
         n_samples = self.TEST_BATCH_MULTIPLIER * self.TEST_BATCH_SIZE
         passes = max(1, -(-n_samples // B))
-        if self.dataset is None:
+        if items is not None:
+            items = list(items)[:max_images]
+        elif self.dataset is None:
             g = torch.Generator().manual_seed(self.seed + 99)
             items = [(torch.randn((self.image_size, self.image_size, 3), generator=g),
                       torch.randint(0, len(self.vocab), (5, 3), generator=g).tolist()) for _ in range(max_images or 2)]
@@ -253,7 +360,7 @@ class SceneGraphGAN(object):
             items = [(self._parseFunction(k), t) for k, t in self.test_items[:max_images]]
         gen = torch.Generator().manual_seed(self.seed + 123)
         toks = torch.empty((B, 3), dtype=torch.int64, device=self.device)
-        r50, r100 = [], []
+        r50, r100, details = [], [], []
         for image, triples in items:
             images = image.unsqueeze(0).expand(B, -1, -1, -1).contiguous().to(self.device)
             fakes, scores = [], []
@@ -268,11 +375,15 @@ class SceneGraphGAN(object):
             a, b = self.recalls(fake, score, triples, reference_literal)
             r50.append(a)
             r100.append(b)
+            details.append({"tokens": fake, "scores": score, "r50": a, "r100": b})
         res = (float(np.mean(r50)), float(np.mean(r100)))
+        ordering = "reference_literal ([N,1] argsort: sample 0 repeated)" if reference_literal else "ascending mean critic score"
         if self.rank == 0 and out_path:
             with open(out_path, "w") as f:
-                f.write("{}\n{}".format(*res))
-        return res
+                f.write("{}\n{}\n# ordering: {}\n".format(res[0], res[1], ordering))
+        if self.rank == 0:
+            print({"R@50": res[0], "R@100": res[1], "ordering": ordering, "images": len(items), "samples_per_image": n_samples})
+        return (res, details) if return_details else res
 
     def sample_triples(self, images, noise=None):
         """tf.argmax(fake_inputs, -1) -> words (train.py:269-275), with the trained weights."""
@@ -280,6 +391,17 @@ class SceneGraphGAN(object):
         toks = torch.empty((images.shape[0], 3), dtype=torch.int64, device=images.device)
         kernels_for(images.device).argmax_rows(logits, toks.view(-1))
         return toks, [[self.reverse_vocab.get(int(i), "UNK") for i in row] for row in toks.cpu()]
+
+
+def _str2bool(v):
+    """--resume of the reference is `type=bool` (train.py:410), which makes every non-empty string - "False" included - true."""
+    if isinstance(v, bool):
+        return v
+    if str(v).strip().lower() in ("1", "true", "t", "yes", "y", "on"):
+        return True
+    if str(v).strip().lower() in ("0", "false", "f", "no", "n", "off", ""):
+        return False
+    raise argparse.ArgumentTypeError("expected a boolean, got %r" % (v,))
 
 
 if __name__ == "__main__":
@@ -293,12 +415,17 @@ if __name__ == "__main__":
     parser.add_argument("--path_to_image_stds", default="./dataset_creation/image_stds.txt")
     parser.add_argument("--batch_size", default=64, help="Batch size defaults", type=int)
     parser.add_argument("--critic_iters", default=10, help="Number of critic iterations per generator iteration", type=int)
-    parser.add_argument("--lambda", default=10, help="WGAN Lipschitz Penalty", type=int)
-    parser.add_argument("--resume", default=False, help="Resume from the last checkpoint", type=bool)
+    parser.add_argument("--lambda", default=10, help="WGAN Lipschitz Penalty", type=float)
+    parser.add_argument("--resume", default=False, nargs="?", const=True, type=_str2bool,
+                        help="Resume from the last checkpoint (--resume, --resume True, --resume False)")
     parser.add_argument("--GPU", default="0", help="Which GPU to use (single-process runs)")
     parser.add_argument("--synthetic", default=None, help="B,S,V: train on synthetic tensors of that shape (no dataset files)")
     parser.add_argument("--max_iterations", default=None, type=int)
     parser.add_argument("--single_stream", action="store_true", help="serial launch order (default: two HIP streams)")
+    parser.add_argument("--no_shuffle_buffer", action="store_true", help="walk the shuffled example list in order (default: through the "
+                                                                         "reference's rolling shuffle buffer of 10 batches, train.py:178)")
+    parser.add_argument("--validate_every", default=None, type=int, help="iterations between validation-loss checks (default: "
+                                                                         "len(train) / 50 on real data as train.py:162, off with --synthetic)")
     parser.add_argument("--recompute_generator_encoder", action="store_true",
                         help="run G's encoder in every update like the reference graph (default: once per iteration, same result)")
     args = parser.parse_args()
@@ -313,5 +440,5 @@ if __name__ == "__main__":
                         path_to_image_means=params["path_to_image_means"], path_to_image_stds=params["path_to_image_stds"],
                         critic_iters=params["critic_iters"], batch_size=params["batch_size"], lambda_=params["lambda"],
                         resume=params["resume"], synthetic=synthetic, two_streams=not params["single_stream"],
-                        reuse_g_encoder=not params["recompute_generator_encoder"])
-    gan.train(max_iterations=params["max_iterations"])
+                        reuse_g_encoder=not params["recompute_generator_encoder"], shuffle_buffer=not params["no_shuffle_buffer"])
+    gan.train(max_iterations=params["max_iterations"], validate_every=params["validate_every"])
