@@ -279,12 +279,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
   auto tap_body = [&](auto par_c, auto tap_c, int cc) {
     constexpr int par = decltype(par_c)::value, tap = decltype(tap_c)::value;
     const int ncc = (cc + 1 == nch) ? 0 : cc + 1;         // (the chunk after the last one re-reads valid weights)
+#ifndef SGG_ABL_NOB
     load_b(std::integral_constant<int, par ^ 1>{}, tap == 8 ? ncc : cc, tap == 8 ? 0 : tap + 1);
+#endif
+#ifndef SGG_ABL_NOSTAGE
     if constexpr (PREFETCH && tap == 6) stage_load();
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // DB: the next chunk's patch (loads issued at tap 6) is split and written to the other buffer inside the last tap's
     // scheduling region, so its ~170 VALU instructions issue in the shadow of this tap's MFMAs
+#ifndef SGG_ABL_NOSTAGE
     if constexpr (DB && PREFETCH && tap == 8) stage_write(lds + (cur ^ 1) * (P * PLANEB));
+#endif
 #ifdef SGG_HALO_PROFILE
     const unsigned long long q0 = __builtin_readcyclecounter();
     if constexpr (PREFETCH && (tap == 6 || tap == 7)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -300,7 +306,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
     mma_kstep(par_c, std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
     PROF(const unsigned long long q3 = __builtin_readcyclecounter();)
+#ifndef SGG_ABL_NOA
     if constexpr (tap < 8) read_a(std::integral_constant<int, par ^ 1>{}, tap + 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     PROF(const unsigned long long q4 = __builtin_readcyclecounter(); pc_lds += q4 - q3;)
     mma_kstep(par_c, std::integral_constant<int, 1>{});
@@ -310,7 +318,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
   };
   auto chunk = [&](auto par0_c, int cc) {
     constexpr int par0 = decltype(par0_c)::value;
+#ifndef SGG_ABL_NOA
     read_a(par0_c, 0);
+#endif
 #define SGG_TAP(T) tap_body(std::integral_constant<int, (par0 + T) & 1>{}, std::integral_constant<int, T>{}, cc)
     SGG_TAP(0); SGG_TAP(1); SGG_TAP(2); SGG_TAP(3); SGG_TAP(4); SGG_TAP(5); SGG_TAP(6); SGG_TAP(7); SGG_TAP(8);
 #undef SGG_TAP
@@ -318,7 +328,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
     PROF(const unsigned long long qc = __builtin_readcyclecounter();)
     if constexpr (DB) {
       if constexpr (!PREFETCH) stage_write(lds + (cur ^ 1) * (P * PLANEB));   // nobody reads the other buffer since the previous barrier
+#ifndef SGG_ABL_NOSTAGE
       cur ^= 1;
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else {
@@ -358,6 +370,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
   stage_write(lds);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  // Timing-only ablation builds (scripts/build_variant_lib.sh <name> -DSGG_ABL_...; results are WRONG): the tap loop without its
+  // B-fragment loads (NOB), its A-fragment reads (NOA), its patch staging (NOSTAGE) or the tile epilogue's stores / statistics
+  // (NOEPI) - the operands are fetched once here and stay in registers, so the loop's MFMA stream is unchanged.
+#ifdef SGG_ABL_NOB
+  load_b(std::integral_constant<int, 1>{}, 0, 1);
+#endif
+#ifdef SGG_ABL_NOA
+  read_a(std::integral_constant<int, 0>{}, 0);
+  read_a(std::integral_constant<int, 1>{}, 1);
+#endif
 
   auto epilogue = [&](int tile) {
     PROF(const unsigned long long qe = __builtin_readcyclecounter();)
@@ -378,7 +400,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
           acc[tm][tn][r] = v;
           lsum += v;
         }
-    if (live) {        // one uniform branch around all stores (a branch per store costs ~64 jumps per tile)
+#ifdef SGG_ABL_NOEPI
+    if (p.B < 0)       // (never true: keeps the code, skips the stores and the statistics)
+#else
+    if (live)          // one uniform branch around all stores (a branch per store costs ~64 jumps per tile)
+#endif
+    {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -389,7 +416,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
             sgg_out_store(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), acc[tm][tn][r]);
           }
     }
+#ifdef SGG_ABL_NOEPI
+    if (p.B < 0) {
+#else
     if (p.tile_stats) {
+#endif
       // (count, mean, M2) of this wave's 64 pixels x WN channels (one 8x8 block: inside one sample); merged per sample
       // with Chan's formula by ln_apply_elu_kernel
       const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));

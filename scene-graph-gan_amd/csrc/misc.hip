@@ -232,29 +232,39 @@ extern "C" int sgg_interpolate(const float* real, const float* fake, const float
 // tf.image.resize_images(image, [oh, ow]) of TF 1.x (bilinear, align_corners=False: the LEGACY grid src = dst * in/out, no half-pixel
 // offset, no antialiasing) followed by (x - mean) / std: train.py:171-172.  One launch per batch: image b is RGB uint8 [H_b][W_b][3]
 // at src + offsets[b] (variable sizes, packed by the host loader); dst [B][oh][ow][3] fp32.  Arithmetic order as TF's kernel
-// (top / bottom row interpolated in x, then in y; no fused multiply-add: equals the host restatement within a few ulps).
+// (top / bottom row interpolated in x, then in y; every product rounded before it is added: no fused multiply-add, see R below).
 __global__ void resize_bilinear_tf1_kernel(const unsigned char* __restrict__ src, const long long* __restrict__ offsets,
                                            const int* __restrict__ heights, const int* __restrict__ widths, float* __restrict__ dst,
                                            int oh, int ow, const float* __restrict__ means, const float* __restrict__ stds) {
+  // TF's CPU kernel rounds every product and difference separately.  The library is built with -ffp-contract=fast, which fuses in
+  // the backend whatever the source says (__fmul_rn / __fsub_rn and `#pragma clang fp contract(off)` included: fx - x0 became
+  // fma(x, sx, -x0), up to 5e-4 on the 0..255 scale against the oracle), so every product passes through an opaque register
+  // copy (R) before it is added or subtracted.
+#define R(x) ({ float r__ = (x); asm volatile("" : "+v"(r__)); r__; })
   const int b = blockIdx.y, y = blockIdx.x;
   const int H = heights[b], W = widths[b];
   const unsigned char* im = src + offsets[b];
-  const float sy = __fdiv_rn((float)H, (float)oh), sx = __fdiv_rn((float)W, (float)ow);
-  const float fy = __fmul_rn((float)y, sy);
+  const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
+  const float fy = R((float)y * sy);
   const int y0 = (int)floorf(fy), y1 = min(y0 + 1, H - 1);
-  const float wy = __fsub_rn(fy, (float)y0);
+  const float wy = fy - (float)y0;
   for (int i = threadIdx.x; i < ow * 3; i += blockDim.x) {
     const int x = i / 3, c = i - 3 * x;
-    const float fx = __fmul_rn((float)x, sx);
+    const float fx = R((float)x * sx);
     const int x0 = (int)floorf(fx), x1 = min(x0 + 1, W - 1);
-    const float wx = __fsub_rn(fx, (float)x0);
+    const float wx = fx - (float)x0;
     const float tl = (float)im[((size_t)y0 * W + x0) * 3 + c], tr = (float)im[((size_t)y0 * W + x1) * 3 + c];
     const float bl = (float)im[((size_t)y1 * W + x0) * 3 + c], br = (float)im[((size_t)y1 * W + x1) * 3 + c];
-    const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), wx));
-    const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), wx));
-    const float v = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), wy));
-    dst[(((size_t)b * oh + y) * ow + x) * 3 + c] = __fdiv_rn(__fsub_rn(v, means[c]), stds[c]);
+    const float dt = tr - tl, db = br - bl;
+    const float pt = R(dt * wx), pb = R(db * wx);
+    const float top = tl + pt, bot = bl + pb;
+    const float dv = bot - top;
+    const float pv = R(dv * wy);
+    const float v = top + pv;
+    const float num = v - means[c];
+    dst[(((size_t)b * oh + y) * ow + x) * 3 + c] = num / stds[c];
   }
+#undef R
 }
 
 extern "C" int sgg_onehot(const long long* labels, float* out, int rows, int V, void* stream) {

@@ -51,8 +51,9 @@ class HeadState:
         self.dOUT = z(np_, R, T_STEPS, Vout)
         self.dXH = [z(np_, R, W) for _ in range(T_STEPS + 1)]
         self.dC = [z(np_, R, H) for _ in range(T_STEPS + 1)]
-        self.dG = z(np_, R, 4 * H)
-        self.dE = z(np_, R, L)
+        # (one buffer per time step: the filter-gradient GEMMs that read them may run on the side stream while the chain moves on)
+        self.dG = [z(np_, R, 4 * H) for _ in range(T_STEPS)]
+        self.dE = [z(np_, R, L) for _ in range(T_STEPS)]
         self.pgrad = z(T_STEPS * R, 10, H)
 
 
@@ -83,11 +84,34 @@ class Head:
         if kind == "D":
             self.W_emb, self.gW_emb = p["W"], g["W"]
         z = lambda *s: torch.zeros(s, device=self.device, dtype=self.dtype)
+        # Second HIP stream for everything OFF the recurrent dependency chain (set by enable_side_stream): the chain of a head pass
+        # is  score GEMM -> attention -> gate GEMM -> LSTM pointwise  per step forward and  decoder dgrad -> LSTM backward -> gate
+        # dgrad -> attention backward -> score dgrad  per step backward - a few short dependent launches each; the embedding and
+        # decoder products of the forward pass and every parameter-gradient GEMM / column sum of the backward pass hang off it and
+        # only have to be complete at the end of the pass.  On one stream they sit between the chain's launches (~330 dependent
+        # launches of 5-15 us per G+D step); on the side stream they run beside it.  Same kernels, same operands, same accumulation
+        # order (one side stream, program order) -> bit-identical results.
+        self.side = None
         self.P = z(B, L)
         self.dP = z(B, L)
         self.dctx = z(B, L, C)
         self._trashP, self._trashCtx = z(B, L), z(B, L, C)
         self._states = {}
+
+    def enable_side_stream(self, stream):
+        self.side = stream
+
+    def _fork(self):
+        """Side stream (or None): everything enqueued so far on the current stream is visible to what is enqueued on it next."""
+        if self.side is None:
+            return None
+        self.side.wait_stream(torch.cuda.current_stream())
+        return self.side
+
+    def join(self):
+        """The current stream waits for the side stream (end of a pass / before the gradients are read)."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def state(self, np_, R, tag=""):
         key = (np_, R, tag)
@@ -110,13 +134,15 @@ class Head:
         train.py:173) - their embedding product tf.matmul(indices, W) (discriminator_with_attention.py:87) is a row gather.
         Fills st.OUT [np, R, 3, Vout]."""
         K, np_, R, ind = self.K, st.np, st.R, self.in_dim
-        K.spatial_mean_fwd(ctx, st.C[0][0], st.XH[0][0][:, ind:])       # plane 1 (tangent of c0 = h0) stays zero
-        for t in range(T_STEPS):
-            K.gemm_nn(flat2(st.C[t]), self.W_c, flat2(st.EC[t]))
-            K.attn_step_fwd(self.P, st.EC[t], ctx, st.AL[t], st.XH[t][:, :, :C])
-            if self.kind == "G":
-                st.XH[t][0][:, C:ind].copy_(u)
-            else:
+        import contextlib
+        on = lambda strm: torch.cuda.stream(strm) if strm is not None else contextlib.nullcontext()
+        # ---- off the chain, known before the loop: the inputs u_t of all three steps (noise copies / embedding products) ----------
+        side = self._fork()
+        with on(side):
+            for t in range(T_STEPS):
+                if self.kind == "G":
+                    st.XH[t][0][:, C:ind].copy_(u)
+                    continue
                 for pl in range(np_):
                     if labels is not None and pl == 0:
                         lo, hi = label_rows
@@ -126,11 +152,20 @@ class Head:
                         K.embed_gather_fwd(labels[:, t], self.W_emb, st.XH[t][0][lo:hi, C:ind])
                     else:
                         K.gemm_nn(u[pl][:, t, :], self.W_emb, st.XH[t][pl][:, C:ind])
+        K.spatial_mean_fwd(ctx, st.C[0][0], st.XH[0][0][:, ind:])       # plane 1 (tangent of c0 = h0) stays zero
+        for t in range(T_STEPS):
+            K.gemm_nn(flat2(st.C[t]), self.W_c, flat2(st.EC[t]))
+            K.attn_step_fwd(self.P, st.EC[t], ctx, st.AL[t], st.XH[t][:, :, :C])
+            if t == 0:
+                self.join()                                             # the inputs of every step are in place
             K.gemm_nn(flat2(st.XH[t]), self.Kk, flat2(st.G[t]))
             K.lstm_fwd(st.G[t], st.C[t], self.ln, st.C[t + 1], st.XH[t + 1][:, :, ind:])
-            K.gemm_nn(st.XH[t + 1][0][:, ind:], self.W_dec, st.OUT[0][:, t, :], self.b_dec)
-            if np_ == 2:
-                K.gemm_nn(st.XH[t + 1][1][:, ind:], self.W_dec, st.OUT[1][:, t, :])
+            # ---- off the chain: the decoder (its output is read after the loop) ---------------------------------------------------
+            with on(self._fork()):
+                K.gemm_nn(st.XH[t + 1][0][:, ind:], self.W_dec, st.OUT[0][:, t, :], self.b_dec)
+                if np_ == 2:
+                    K.gemm_nn(st.XH[t + 1][1][:, ind:], self.W_dec, st.OUT[1][:, t, :])
+        self.join()
         return st.OUT
 
     # ------------------------------------------------------------------------------------------------
@@ -150,47 +185,67 @@ class Head:
         accumulated); every row gets its data cotangents (st.dXH[t][:, :, 512:in] = cotangent of u_t).
         labels / label_rows as in forward: the embedding gradient of the one-hot rows is a row scatter-add."""
         K, np_, R, ind = self.K, st.np, st.R, self.in_dim
+        import contextlib
+        on = lambda strm: torch.cuda.stream(strm) if strm is not None else contextlib.nullcontext()
         pc = np_ - 1                                    # plane holding cotangents of real quantities
         assert R_w % self.B == 0 and (np_ == 1 or R_w == R)
+        # ---- off the chain, known before the loop: the decoder's parameter gradients (operands: the forward's h_t and dOUT) --------
+        if R_w:
+            with on(self._fork()):
+                for t in range(T_STEPS - 1, -1, -1):
+                    dout = st.dOUT[:, :, t, :]
+                    self._wgrad(st.XH[t + 1][:, :, ind:], dout, self.gW_dec, R_w)
+                    K.colsum(dout[pc][:R_w], self.gb_dec, True)
         for t in range(T_STEPS - 1, -1, -1):
             dout = st.dOUT[:, :, t, :]
             dh = st.dXH[t + 1][:, :, ind:]
+            dG, dE = st.dG[t], st.dE[t]
             for pl in range(np_):
                 K.gemm_nt(dout[pl], self.W_dec, dh[pl], accumulate=(t < T_STEPS - 1))
-            if R_w:
-                self._wgrad(st.XH[t + 1][:, :, ind:], dout, self.gW_dec, R_w)
-                K.colsum(dout[pc][:R_w], self.gb_dec, True)
-            K.lstm_bwd(st.G[t], st.C[t], self.ln, dh, st.dC[t + 1] if t < T_STEPS - 1 else None, st.dG, st.dC[t],
+            K.lstm_bwd(st.G[t], st.C[t], self.ln, dh, st.dC[t + 1] if t < T_STEPS - 1 else None, dG, st.dC[t],
                        st.pgrad[t * R:(t + 1) * R])
-            self._wgrad(st.XH[t], st.dG, self.gKk, R_w)
-            K.gemm_nt(flat2(st.dG), self.Kk, flat2(st.dXH[t]))
-            if self.kind == "D" and R_w:
-                if labels is not None and np_ == 1:
-                    lo, hi = label_rows
-                    assert hi <= R_w
-                    for a, b in ((0, lo), (hi, R_w)):
-                        if b > a:
-                            K.gemm_tn(u[0][a:b, t, :], st.dXH[t][0][a:b, C:ind], self.gW_emb, accumulate=True)
-                    K.embed_gather_bwd(labels[:, t], st.dXH[t][0][lo:hi, C:ind], self.gW_emb)
-                else:
-                    self._wgrad([x[:, t, :] for x in u], st.dXH[t][:, :, C:ind], self.gW_emb, R_w)
+            K.gemm_nt(flat2(dG), self.Kk, flat2(st.dXH[t]))
             dz = st.dXH[t][:, :, :C]
             if R_w:
-                K.attn_step_bwd(ctx, st.AL[t][:, :R_w], dz[:, :R_w], st.dE[:, :R_w], self.dP, self.dctx, True)
+                K.attn_step_bwd(ctx, st.AL[t][:, :R_w], dz[:, :R_w], dE[:, :R_w], self.dP, self.dctx, True)
             if R_w < R:
-                K.attn_step_bwd(ctx, st.AL[t][:, R_w:], dz[:, R_w:], st.dE[:, R_w:], self._trashP, self._trashCtx, False)
-            self._wgrad(st.C[t], st.dE, self.gW_c, R_w)
-            K.gemm_nt(flat2(st.dE), self.W_c, flat2(st.dC[t]), accumulate=True)
+                K.attn_step_bwd(ctx, st.AL[t][:, R_w:], dz[:, R_w:], dE[:, R_w:], self._trashP, self._trashCtx, False)
+            K.gemm_nt(flat2(dE), self.W_c, flat2(st.dC[t]), accumulate=True)
+            # ---- off the chain: the parameter gradients of step t (gate kernel, embedding, score weights), in the serial order ------
+            if R_w:
+                with on(self._fork()):
+                    self._wgrad(st.XH[t], dG, self.gKk, R_w)
+                    if self.kind == "D":
+                        if labels is not None and np_ == 1:
+                            lo, hi = label_rows
+                            assert hi <= R_w
+                            for a, b in ((0, lo), (hi, R_w)):
+                                if b > a:
+                                    K.gemm_tn(u[0][a:b, t, :], st.dXH[t][0][a:b, C:ind], self.gW_emb, accumulate=True)
+                            K.embed_gather_bwd(labels[:, t], st.dXH[t][0][lo:hi, C:ind], self.gW_emb)
+                        else:
+                            self._wgrad([x[:, t, :] for x in u], st.dXH[t][:, :, C:ind], self.gW_emb, R_w)
+                    self._wgrad(st.C[t], dE, self.gW_c, R_w)
         if R_w:
             K.spatial_mean_bwd(st.dC[0][pc][:R_w], st.dXH[0][pc][:R_w, ind:], self.dctx, True)
-            for t in range(T_STEPS):
-                K.colsum(st.pgrad[t * R:t * R + R_w].view(R_w, 10 * H), self.gln, True)
+            with on(self._fork()):
+                for t in range(T_STEPS):
+                    K.colsum(st.pgrad[t * R:t * R + R_w].view(R_w, 10 * H), self.gln, True)
+        self.join()
 
     def finish_backward(self, ctx):
         """Gradients that flow through the step-invariant score P (after every head pass of the step)."""
         K, B, L = self.K, self.B, self.L
         ctx_flat = ctx.view(B, L * C)
-        K.colsum(self.dP, self.gb_att, True)
-        K.attn_ctx_wgrad(ctx_flat, self.dP, self.gW_ctx, accumulate=True)
+        # the parameter gradients (79 MB of attention weights) beside the dgrad that the encoder backward waits for; joined by
+        # join() before the gradients are read (GanStep: before the all-reduce / Adam step)
+        side = self._fork()
+        if side is not None:
+            with torch.cuda.stream(side):
+                K.colsum(self.dP, self.gb_att, True)
+                K.attn_ctx_wgrad(ctx_flat, self.dP, self.gW_ctx, accumulate=True)
+        else:
+            K.colsum(self.dP, self.gb_att, True)
+            K.attn_ctx_wgrad(ctx_flat, self.dP, self.gW_ctx, accumulate=True)
         K.attn_ctx_dgrad(self.dP, self.W_ctx, self.dctx.view(B, L * C), accumulate=True)
         return self.dctx

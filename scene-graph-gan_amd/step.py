@@ -78,7 +78,7 @@ class GanStep:
     across data-parallel ranks and returns the scale to apply to the gradient (1/world_size)."""
 
     def __init__(self, K, V, S, B, lam=10.0, E=EMBED_DIM, g_state=None, d_state=None, dtype=torch.float32, reducer=None,
-                 G=None, D=None, overlap_streams=False):
+                 G=None, D=None, overlap_streams=False, head_side_stream=True):
         self.K, self.V, self.S, self.B, self.lam = K, V, S, B, float(lam)
         self.G = G if G is not None else Network(K, "G", V, S, B, E, dtype=dtype, state_dict=g_state)
         self.D = D if D is not None else Network(K, "D", V, S, B, E, dtype=dtype, state_dict=d_state)
@@ -102,6 +102,12 @@ class GanStep:
             # backward: filter gradients beside the dgrad -> LayerNorm-backward chain (trunk.enable_wgrad_overlap)
             self.G.trunk.enable_wgrad_overlap(self.side)
             self.D.trunk.enable_wgrad_overlap(self.side)
+        # The recurrent heads are chains of short dependent launches; everything off the chain (embedding / decoder products,
+        # every parameter-gradient GEMM) runs on a stream of its own beside it (head.py).  Always on (also in bench.py's serial
+        # schedule): no convolution kernel runs during a head pass, bit-identical results.
+        self.head_side = torch.cuda.Stream(device=dev) if (head_side_stream and dev.type == "cuda") else None
+        self.G.head.enable_side_stream(self.head_side)
+        self.D.head.enable_side_stream(self.head_side)
 
     # ------------------------------------------------------------------------------------------------
     def generator_forward(self, images, noise, for_backward=True):
@@ -200,6 +206,7 @@ class GanStep:
         # W enters g = delta_e @ W^T directly as well: handled by the tangent input v @ W above (u2[1])
         dctx = D.head.finish_backward(ctx)
         D.trunk.backward(dctx)
+        D.head.join()
         D.update(self.reducer)
         return self.d_losses
 
@@ -260,6 +267,7 @@ class GanStep:
         G.head.backward(gst, gctx, None, R_w=B)
         dctx = G.head.finish_backward(gctx)
         G.trunk.backward(dctx)
+        G.head.join()
         G.update(self.reducer)
         return self.g_losses
 

@@ -169,3 +169,27 @@ def test_step_is_unchanged_beside_collective_like_traffic(hip):
     bad = [k for k in ref2 if not torch.equal(ref2[k], got2[k])]
     assert not bad, "two-stream schedule beside ring-like traffic: %d tensors differ, first %s" % (len(bad), bad[:3])
     assert all(torch.equal(ref[k], ref2[k]) for k in ref)
+
+
+def test_head_side_stream_is_bitwise_the_single_stream_schedule(hip):
+    """head.py runs everything off the recurrent dependency chain (embedding / decoder products, every parameter-gradient GEMM and
+    column sum of the heads, the attention weights' gradient) on a second stream beside the chain.  Same kernels, same operands,
+    same accumulation order: after two iterations of two critic updates every weight, gradient and activation equals the
+    single-stream schedule's, also in combination with the two-stream encoder schedule."""
+    img, lab = _inputs()[:2]
+
+    def run(**kw):
+        gs = _new_step(hip, **kw)
+        for it in range(2):
+            noises = [O.synth_noise(B, 10 * it + i).cuda() for i in range(3)]
+            alphas = [O.synth_alpha(B, 10 * it + i).reshape(B).cuda() for i in range(2)]
+            gs.train_iteration(img, lab, noises, alphas, critic_iters=2)
+        gs.flush()
+        return _snapshot(gs)
+
+    ref = run(head_side_stream=False)
+    for kw in ({"head_side_stream": True}, {"head_side_stream": True, "overlap_streams": True}):
+        for rep in range(3):
+            got = run(**kw)
+            bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+            assert not bad, "%s repetition %d: %d tensors differ, first %s" % (kw, rep, len(bad), bad[:3])
