@@ -40,6 +40,9 @@ extern "C" int sgg_halo_prof_read(unsigned long long* out, int reset) {
 #ifndef SGG_HALO_DB_MAX
 #define SGG_HALO_DB_MAX 65536   // two patch buffers when they fit in this many bytes of LDS (a gfx950 workgroup may use up to 160 KB; measured: see DESIGN.md)
 #endif
+#ifndef SGG_WIDE_STORE
+#define SGG_WIDE_STORE 1        // 16-byte output stores through an in-register quad transpose (sgg_common.h); 0: 4-byte stores
+#endif
 #define HALO_PITCH 12
 #define HALO_BLKB (10 * HALO_PITCH * 64)   // bytes of one plane of one block's patch
 
@@ -50,12 +53,18 @@ __device__ __forceinline__ int halo_sw(int ry, int rx) { return ((rx >> 2) & 1) 
 // costs ~110 spilled VGPRs at the merge.
 // LNP: LN prologue - src is the producing layer's pre-LayerNorm output, normalised + ELU'd while the patch is staged.
 // ONE: single-piece mode (precision 1 / 4): one 16-bit plane, one MFMA per product.
-template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH, bool LNP, bool ONE = false>
+// WB: 8x8 blocks per wave.  1: a wave owns one block x WN columns (TM = 2 row tiles); 2: two blocks (TM = 4) - with WGM = 1, WGN = 4
+// the four waves of a workgroup take 32 output columns each of the SAME 128 pixels: a B fragment (L2 -> L1 -> registers, 64 B/clk
+// per CU) then feeds four row tiles instead of two, the A fragments (LDS, 256 B/clk per CU) are read by all four waves: the two
+// operand paths carry 4 KiB / 16 KiB per wave and tap instead of 8 / 8.  A fragments are then double-buffered per k-step
+// (a[k-step][tm]) instead of per tap, which keeps them at 64 registers.
+template <int NB, int BN, int WGM, int WGN, bool HALF, bool PREFETCH, bool ONECH, bool LNP, bool ONE = false, int WB = 1>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParams p) {
   constexpr int P = ONE ? 1 : 2;
-  constexpr int WN = BN / WGN, TM = 2, TN = WN / 32;
+  constexpr int WN = BN / WGN, TM = 2 * WB, TN = WN / 32;
   constexpr int THREADS = 64 * WGM * WGN;       // four waves (two workgroups per CU) or two (four workgroups per CU, one patch buffer)
-  static_assert((WGM * WGN == 4 || WGM * WGN == 2) && NB * 64 / WGM == 64 && WN % 32 == 0 && TN >= 1, "a wave owns one 8x8 block x WN columns");
+  static_assert((WGM * WGN == 4 || WGM * WGN == 2) && NB * 64 / WGM == 64 * WB && WN % 32 == 0 && TN >= 1 && (WB == 1 || WB == 2),
+                "a wave owns WB 8x8 blocks x WN columns");
   constexpr int PLANEB = NB * HALO_BLKB;
   constexpr int ITEMS = NB * 400;                       // (block, patch pixel, 8-channel group)
   constexpr int NPASS = (ITEMS + THREADS - 1) / THREADS;
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
   const int n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wblk = wave / WGN, wn0 = (wave % WGN) * WN;
+  const int wblk = (wave / WGN) * WB, wn0 = (wave % WGN) * WN;      // first block of this wave inside the tile
 
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
@@ -239,9 +248,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
   // waited for the loads it had just issued: the whole L2 latency exposed per tap.)
   // (Reading the A fragments of tap t+1 between the two k-steps of tap t - software pipelining inside the wave - was
   //  measured: no gain, 32 more VGPRs.)
-  u32x4 a[2][TM][2][P];
-  auto read_a = [&](auto buf_c, int tap) {
-    constexpr int buf = decltype(buf_c)::value;
+  // WB == 1: a[tap parity][tm][k-step][plane] (the fragments of tap t+1 are read between the two k-steps of tap t);
+  // WB == 2: a[k-step][tm][0][plane] (the fragments of k-step k+1 are read in front of the MFMAs of k-step k)
+  constexpr int AKS = WB == 1 ? 2 : 1;
+  u32x4 a[2][TM][AKS][P];
+  // A fragments of one tap from the resident patch: k-steps [ks0, ks0 + nks) into a[buf][tm][ks - (WB == 1 ? 0 : ks0)]
+  auto read_a_ks = [&](auto buf_c, int tap, auto ks0_c, auto nks_c) {
+    constexpr int buf = decltype(buf_c)::value, ks0 = decltype(ks0_c)::value, nks = decltype(nks_c)::value;
     const int kh = tap / 3, kw = tap % 3;
     const int dyy = p.flip ? 2 - kh : kh, dxx = p.flip ? 2 - kw : kw;
     // (opaque to the optimiser: otherwise the 36 per-tap LDS addresses are hoisted out of the chunk loop and spilled,
@@ -251,28 +264,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
     const unsigned char* patch_w = lds + (DB ? cur * (P * PLANEB) : 0) + wblk * HALO_BLKB;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      const int ry = tm * 4 + pyv + dyy, rx = pxv + dxx;
-      const unsigned char* row = patch_w + (ry * HALO_PITCH + rx) * 64;
+      const int ry = (tm & 1) * 4 + pyv + dyy, rx = pxv + dxx;           // (tm >> 1: which of the wave's blocks)
+      const unsigned char* row = patch_w + (tm >> 1) * HALO_BLKB + (ry * HALO_PITCH + rx) * 64;
       const int hs = halo_sw(ry, rx);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = ks0; ks < ks0 + nks; ++ks)
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
-          a[buf][tm][ks][pp] = *reinterpret_cast<const u32x4*>(row + pp * PLANEB + (((2 * ks + h) ^ hs) << 4));
+          a[buf][tm][WB == 1 ? ks : 0][pp] = *reinterpret_cast<const u32x4*>(row + pp * PLANEB + (((2 * ks + h) ^ hs) << 4));
     }
   };
+  auto read_a = [&](auto buf_c, int tap) { read_a_ks(buf_c, tap, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}); };
   auto mma_kstep = [&](auto par_c, auto ks_c) {
     constexpr int par = decltype(par_c)::value, ks = decltype(ks_c)::value;
+    constexpr int ab = WB == 1 ? par : ks, ak = WB == 1 ? ks : 0;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         f32x16 d = acc[tm][tn];
         if constexpr (P == 2) {
-          d = mfma16<HALF>(a[par][tm][ks][1], rb[par][tn][ks][0], d);
-          d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][1], d);
+          d = mfma16<HALF>(a[ab][tm][ak][1], rb[par][tn][ks][0], d);
+          d = mfma16<HALF>(a[ab][tm][ak][0], rb[par][tn][ks][1], d);
         }
-        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][0], d);
+        d = mfma16<HALF>(a[ab][tm][ak][0], rb[par][tn][ks][0], d);
         acc[tm][tn] = d;
       }
   };
@@ -302,6 +317,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
     // A fragments of tap t+1 are read between the two k-steps of tap t (the in-kernel profile shows 11 % of a wave's time
     // in issue + wait of these reads when they sit in front of the MFMAs)
     PROF(const unsigned long long q2 = __builtin_readcyclecounter();)
+    if constexpr (WB == 2) {
+      // k-step granular: [read k-step 1 of this tap] MFMAs of k-step 0 [read k-step 0 of the next tap] MFMAs of k-step 1
+#ifndef SGG_ABL_NOA
+      read_a_ks(std::integral_constant<int, 1>{}, tap, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      SGG_PRIO_HI();
+      mma_kstep(par_c, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef SGG_ABL_NOA
+      if constexpr (tap < 8) read_a_ks(std::integral_constant<int, 0>{}, tap + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      mma_kstep(par_c, std::integral_constant<int, 1>{});
+      SGG_PRIO_LO();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     SGG_PRIO_HI();
     mma_kstep(par_c, std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -315,11 +347,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
     SGG_PRIO_LO();
     __builtin_amdgcn_sched_barrier(0);
     PROF(pc_mfma += (__builtin_readcyclecounter() - q4) + (q3 - q2);)
+    }
   };
   auto chunk = [&](auto par0_c, int cc) {
     constexpr int par0 = decltype(par0_c)::value;
 #ifndef SGG_ABL_NOA
-    read_a(par0_c, 0);
+    if constexpr (WB == 2) read_a_ks(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    else read_a(par0_c, 0);
 #endif
 #define SGG_TAP(T) tap_body(std::integral_constant<int, (par0 + T) & 1>{}, std::integral_constant<int, T>{}, cc)
     SGG_TAP(0); SGG_TAP(1); SGG_TAP(2); SGG_TAP(3); SGG_TAP(4); SGG_TAP(5); SGG_TAP(6); SGG_TAP(7); SGG_TAP(8);
@@ -345,13 +379,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
   };
 
   // this wave's output block: global block row and column, advanced by NB per tile
-  int o_grow, o_bx;
-  {
-    const int beta = mt_begin * NB + wblk;
-    o_grow = beta / p.bw;
-    o_bx = beta % p.bw;
+  int o_grow[WB], o_bx[WB];
+#pragma unroll
+  for (int wb = 0; wb < WB; ++wb) {
+    const int beta = mt_begin * NB + wblk + wb;
+    o_grow[wb] = beta / p.bw;
+    o_bx[wb] = beta % p.bw;
   }
-  const unsigned o_lane_b = (unsigned)((4 * h * p.out_ps) + (lane & 31)) * 4u;     // per-lane byte offset inside a block
+  // per-lane byte offset inside a block.  After the quad transpose of the accumulators (sgg_quad_transpose4) lane (h, g, k) =
+  // (lane >> 5, (lane & 31) >> 2, lane & 3) holds pixel column 4h + k of a block row and output channels 4g .. 4g+3 of its 32-column
+  // group: one 16-byte store per four accumulator registers (SGG_WIDE_STORE 0: the accumulators as they stand, 4 bytes per lane)
+#if SGG_WIDE_STORE
+  const unsigned o_lane_b = (unsigned)(((4 * h + (lane & 3)) * p.out_ps) + ((lane & 31) >> 2) * 4) * 4u;
+#else
+  const unsigned o_lane_b = (unsigned)((4 * h * p.out_ps) + (lane & 31)) * 4u;
+#endif
   int o_goff[TN];                                                                   // float offset of this wave's 32-column groups
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -384,71 +426,91 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
   auto epilogue = [&](int tile) {
     PROF(const unsigned long long qe = __builtin_readcyclecounter();)
     // ---- tile epilogue: unscale, + bias, store; optionally this wave's LayerNorm partial statistics; clear ----------
-    const int beta = tile * NB + wblk;
-    const bool live = beta < p.nblk;
-    // uniform (scalar) pointer to the block's first pixel; per store: scalar row/pixel offset + one per-lane byte offset
-    const char* ob = reinterpret_cast<const char*>(p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.out_ps);
-    float lsum = 0.f;
+    // (per block of the wave: wb = 0 .. WB-1, row tiles 2 wb and 2 wb + 1)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // (two exact power-of-two factors: |ea|, |eb| <= 100 keeps each one a normal float)
-          const float v = HALF ? fmaf(acc[tm][tn][r] * us_a, us_b, bias_v[tn]) : acc[tm][tn][r] + bias_v[tn];
-          acc[tm][tn][r] = v;
-          lsum += v;
-        }
-#ifdef SGG_ABL_NOEPI
-    if (p.B < 0)       // (never true: keeps the code, skips the stores and the statistics)
-#else
-    if (live)          // one uniform branch around all stores (a branch per store costs ~64 jumps per tile)
-#endif
-    {
+    for (int wb = 0; wb < WB; ++wb) {
+      const int beta = tile * NB + wblk + wb;
+      const bool live = beta < p.nblk;
+      // uniform (scalar) pointer to the block's first pixel; per store: scalar row/pixel offset + one per-lane byte offset
+      const char* ob = reinterpret_cast<const char*>(p.out + (size_t)(o_grow[wb] * 8) * wn + (size_t)(o_bx[wb] * 8) * p.out_ps);
+      float lsum = 0.f;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const size_t so = ((size_t)(tm * 4 + (r >> 2)) * wn + (size_t)(r & 3) * p.out_ps + o_goff[tn]) * sizeof(float);   // scalar
-            sgg_out_store(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), acc[tm][tn][r]);
+            // (two exact power-of-two factors: |ea|, |eb| <= 100 keeps each one a normal float)
+            const int tm = 2 * wb + t2;
+            const float v = HALF ? fmaf(acc[tm][tn][r] * us_a, us_b, bias_v[tn]) : acc[tm][tn][r] + bias_v[tn];
+            acc[tm][tn][r] = v;
+            lsum += v;
           }
-    }
-#ifdef SGG_ABL_NOEPI
-    if (p.B < 0) {
+#if defined(SGG_ABL_NOEPI) || defined(SGG_ABL_NOSTORE)
+      if (p.B < 0)       // (never true: keeps the code, skips the stores and the statistics)
 #else
-    if (p.tile_stats) {
+      if (live)          // one uniform branch around all stores (a branch per store costs ~64 jumps per tile)
 #endif
-      // (count, mean, M2) of this wave's 64 pixels x WN channels (one 8x8 block: inside one sample); merged per sample
-      // with Chan's formula by ln_apply_elu_kernel
-      const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));
-      float q = 0.f, dm = 0.f;
+      {
+#if SGG_WIDE_STORE
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+          for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[tm][tn][r] - mean_w;
-            q += d * d;
-            dm = fmaxf(dm, fabsf(d));
-          }
-      q = wave_sum(q);
-      dm = wave_max(dm);
-      if (lane == 0 && live) {
-        float* o = p.tile_stats + ((size_t)beta * (p.N / WN) + (n0 + wn0) / WN) * SGG_TS;
-        o[0] = (float)(64 * WN);
-        o[1] = mean_w;
-        o[2] = q;
-        o[3] = dm;
+            for (int q = 0; q < 4; ++q) {
+              const int tm = 2 * wb + t2;
+              float v0 = acc[tm][tn][4 * q], v1 = acc[tm][tn][4 * q + 1], v2 = acc[tm][tn][4 * q + 2], v3 = acc[tm][tn][4 * q + 3];
+              sgg_quad_transpose4(v0, v1, v2, v3, lane);
+              const size_t so = ((size_t)(t2 * 4 + q) * wn + o_goff[tn]) * sizeof(float);   // scalar: block row 4 t2 + q
+              sgg_out_store4(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), f32x4{v0, v1, v2, v3});
+            }
+#else
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const size_t so = ((size_t)(t2 * 4 + (r >> 2)) * wn + (size_t)(r & 3) * p.out_ps + o_goff[tn]) * sizeof(float);   // scalar
+              sgg_out_store(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), acc[2 * wb + t2][tn][r]);
+            }
+#endif
       }
+#if defined(SGG_ABL_NOEPI) || defined(SGG_ABL_NOSTATS)
+      if (p.B < 0) {
+#else
+      if (p.tile_stats) {
+#endif
+        // (count, mean, M2) of this wave's 64 pixels x WN channels (one 8x8 block: inside one sample); merged per sample
+        // with Chan's formula by ln_apply_elu_kernel
+        const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));
+        float q = 0.f, dm = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[2 * wb + t2][tn][r] - mean_w;
+              q += d * d;
+              dm = fmaxf(dm, fabsf(d));
+            }
+        q = wave_sum(q);
+        dm = wave_max(dm);
+        if (lane == 0 && live) {
+          float* o = p.tile_stats + ((size_t)beta * (p.N / WN) + (n0 + wn0) / WN) * SGG_TS;
+          o[0] = (float)(64 * WN);
+          o[1] = mean_w;
+          o[2] = q;
+          o[3] = dm;
+        }
+      }
+      o_bx[wb] += adv_cols;
+      o_grow[wb] += adv_rows;
+      if (o_bx[wb] >= p.bw) { o_bx[wb] -= p.bw; ++o_grow[wb]; }
     }
     acc_zero<TM, TN>(acc);
-    o_bx += adv_cols;
-    o_grow += adv_rows;
-    if (o_bx >= p.bw) { o_bx -= p.bw; ++o_grow; }
     PROF(pc_epi += __builtin_readcyclecounter() - qe;)
   };
 
@@ -558,12 +620,19 @@ int sgg_halo_applicable(int KH, int KW, int stride, int H, int W, int C, int N, 
 #ifndef SGG_HALO_N64_NB2
 #define SGG_HALO_N64_NB2 1
 #endif
-int sgg_halo_stats_cols(int N) { return (N % (SGG_HALO_N64_NB2 ? 128 : 64) == 0) ? 64 : 32; }
+// 128-column layers: -DSGG_HALO_N128_WB2=1 = four waves of (two blocks x 32 columns) instead of 2 x 2 waves of (one block x 64 columns)
+#ifndef SGG_HALO_N128_WB2
+#define SGG_HALO_N128_WB2 0
+#endif
+int sgg_halo_stats_cols(int N) {
+  if (N % 128 == 0) return SGG_HALO_N128_WB2 ? 32 : 64;
+  return (N % (SGG_HALO_N64_NB2 ? 128 : 64) == 0) ? 64 : 32;
+}
 
 void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
   HaloParams p = p_;
   const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);   // (the LN prologue exists in the two-piece modes only: callers check)
-#define SGG_HALO(NB, BN, WGM, WGN, PF)                                                                       \
+#define SGG_HALO(NB, BN, WGM, WGN, PF, WB)                                                                   \
   do {                                                                                                       \
     const int mtiles = sgg_cdiv(p.nblk, NB), ntn = p.N / BN;                                                 \
     int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       /* (tile, n-tile) pairs an XCD owns */                    \
@@ -572,26 +641,28 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
     gx = sgg_cdiv(gx, ntn) * ntn;                                                                            \
     p.gx = gx;                                                                                               \
     const dim3 grid((unsigned)(8 * gx));                                                                     \
+    const dim3 blk(64 * WGM * WGN);                                                                          \
     if (one) {                                                                                                                          \
-      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);   \
-      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);      \
-      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p); \
-      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);               \
+      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false, true, WB>), grid, blk, 0, st, p);   \
+      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false, true, WB>), grid, blk, 0, st, p);      \
+      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false, true, WB>), grid, blk, 0, st, p); \
+      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false, true, WB>), grid, blk, 0, st, p);               \
     } else if (p.ln_stats) {                                                                                                            \
-      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, true>), grid, dim3(64 * WGM * WGN), 0, st, p);   \
-      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);      \
-      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, true>), grid, dim3(64 * WGM * WGN), 0, st, p); \
-      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, true>), grid, dim3(64 * WGM * WGN), 0, st, p);               \
-    } else if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false>), grid, dim3(64 * WGM * WGN), 0, st, p); \
-    else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false>), grid, dim3(64 * WGM * WGN), 0, st, p);       \
-    else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false>), grid, dim3(64 * WGM * WGN), 0, st, p);  \
-    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false>), grid, dim3(64 * WGM * WGN), 0, st, p);                \
+      if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, true, false, WB>), grid, blk, 0, st, p);   \
+      else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, true, false, WB>), grid, blk, 0, st, p);      \
+      else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, true, false, WB>), grid, blk, 0, st, p); \
+      else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, true, false, WB>), grid, blk, 0, st, p);               \
+    } else if (half && p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, true, false, false, WB>), grid, blk, 0, st, p); \
+    else if (half) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, true, PF, false, false, false, WB>), grid, blk, 0, st, p);       \
+    else if (p.C == 32) hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, true, false, false, WB>), grid, blk, 0, st, p);  \
+    else hipLaunchKernelGGL((conv_halo3_kernel<NB, BN, WGM, WGN, false, PF, false, false, false, WB>), grid, blk, 0, st, p);                \
   } while (0)
-  if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true);
-  else if (p.N % 64 == 0 && SGG_HALO_N64_NB2) SGG_HALO(2, 64, 2, 2, true);
-  else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false);      // (with PREFETCH: 35 spilled VGPRs at the 256-register budget of two waves per SIMD)
-  else if (SGG_HALO_N32_W2) SGG_HALO(2, 32, 2, 1, true);
-  else SGG_HALO(4, 32, 4, 1, true);
+  if (p.N % 128 == 0 && SGG_HALO_N128_WB2) SGG_HALO(2, 128, 1, 4, true, 2);      // four waves x (two blocks x 32 columns)
+  else if (p.N % 128 == 0) SGG_HALO(2, 128, 2, 2, true, 1);
+  else if (p.N % 64 == 0 && SGG_HALO_N64_NB2) SGG_HALO(2, 64, 2, 2, true, 1);
+  else if (p.N % 64 == 0) SGG_HALO(4, 64, 4, 1, false, 1);      // (with PREFETCH: 35 spilled VGPRs at the 256-register budget of two waves per SIMD)
+  else if (SGG_HALO_N32_W2) SGG_HALO(2, 32, 2, 1, true, 1);
+  else SGG_HALO(4, 32, 4, 1, true, 1);
 #undef SGG_HALO
 }
 

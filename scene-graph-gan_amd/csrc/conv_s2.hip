@@ -29,6 +29,9 @@
 #include "conv_halo.h"
 #include <type_traits>
 
+#ifndef SGG_WIDE_STORE
+#define SGG_WIDE_STORE 1        // 16-byte output stores through an in-register quad transpose (sgg_common.h); 0: 4-byte stores
+#endif
 #define S2_BAND 224                   // positions per band in the 7-tile variant (what LayerNorm partials are defined on)
 #define S2_MAXSLOTS 496               // 2 buffers x 2 planes x 496 x 32 B + the row tables stay inside 64 KB of static LDS
 #define S2_ZSLOT (S2_MAXSLOTS - 1)    // never part of a patch: staged as zeros (out-of-range loads), read by edge lanes
@@ -309,6 +312,26 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         lsum += v;
       }
     char* ob = reinterpret_cast<char*>(p.out) + cls_off_bytes + (size_t)(n0 + i) * 4;
+#if SGG_WIDE_STORE
+    if (p.ksplit <= 1) {
+      // 16-byte stores: after the quad transpose lane (h, g, k) = (lane >> 5, i >> 2, i & 3) holds position rq * 8 + 4 h + k of the
+      // row tile and channels 4g .. 4g+3 (sgg_common.h: sgg_quad_transpose4)
+      char* ow = reinterpret_cast<char*>(p.out) + cls_off_bytes + (size_t)(n0 + (i & ~3)) * 4;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float v0 = acc[t][rq * 4], v1 = acc[t][rq * 4 + 1], v2 = acc[t][rq * 4 + 2], v3 = acc[t][rq * 4 + 3];
+          sgg_quad_transpose4(v0, v1, v2, v3, lane);
+          const int o = rowtab[tabsel][t * 32 + rq * 8 + 4 * h + (i & 3)];
+          if (o >= 0) sgg_out_store4(reinterpret_cast<float*>(ow + o), f32x4{v0, v1, v2, v3});
+        }
+    }
+    const bool narrow = p.ksplit > 1;
+#else
+    const bool narrow = true;
+#endif
+    if (narrow) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -326,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
           if (o4.w >= 0) sgg_out_store(reinterpret_cast<float*>(ob + o4.w), acc[t][rq * 4 + 3]);
         }
       }
+    }
     if constexpr (!DGRAD) {
       if (p.tile_stats) {
         // (count, mean, M2) of this wave's 224 positions x 32 channels (bands align with samples: host check)

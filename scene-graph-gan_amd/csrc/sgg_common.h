@@ -144,3 +144,40 @@ __device__ __forceinline__ void sgg_out_store(float* p, float v) {
   *p = v;
 #endif
 }
+__device__ __forceinline__ void sgg_out_store4(float* p, const f32x4& v) {     // p 16-byte aligned
+#if SGG_CONV_NT_STORE
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
+// 4x4 transpose inside every quad of lanes (lanes 4g .. 4g+3), in registers (DPP quad permutes, no LDS):
+//     before: register j of lane 4g+k holds M[j][k]        after: register j of lane 4g+k holds M[k][j]
+// A 32x32 MFMA accumulator has its COLUMN on the lane and four consecutive ROWS in registers 4q .. 4q+3, so a row-major output
+// (row = pixel, column = channel) can only be stored 4 bytes per lane as it stands: 64 `global_store_dword` per 64x64 tile and
+// wave, and the epilogue is bound by the store ISSUE rate of the CU (~8 B/clk), not by bandwidth (cdna_hip_programming.md T21).
+// Transposed, lane 4g+k holds row k, columns 4g .. 4g+3 in four registers: ONE 16-byte store where there were four 4-byte ones.
+__device__ __forceinline__ float sgg_quad_perm_1032(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+}
+__device__ __forceinline__ float sgg_quad_perm_2301(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+}
+__device__ __forceinline__ void sgg_quad_transpose4(float& a0, float& a1, float& a2, float& a3, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  // (every permute is evaluated by ALL lanes before anything is selected: a DPP read of a lane that sits in the untaken arm of a
+  //  conditional expression returns zero)
+  // stage 1: element (j, k) with (j ^ k) & 1 comes from (j ^ 1, k ^ 1)
+  const float x0 = sgg_quad_perm_1032(a0), x1 = sgg_quad_perm_1032(a1), x2 = sgg_quad_perm_1032(a2), x3 = sgg_quad_perm_1032(a3);
+  const float t0 = b0 ? x1 : a0;
+  const float t1 = b0 ? a1 : x0;
+  const float t2 = b0 ? x3 : a2;
+  const float t3 = b0 ? a3 : x2;
+  // stage 2: element (j, k) with (j ^ k) & 2 comes from (j ^ 2, k ^ 2)
+  const float y0 = sgg_quad_perm_2301(t0), y1 = sgg_quad_perm_2301(t1), y2 = sgg_quad_perm_2301(t2), y3 = sgg_quad_perm_2301(t3);
+  a0 = b1 ? y2 : t0;
+  a1 = b1 ? y3 : t1;
+  a2 = b1 ? t2 : y0;
+  a3 = b1 ? t3 : y1;
+}
