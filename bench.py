@@ -301,9 +301,9 @@ def main():
                     help="conv contraction: 2 = scaled fp16 pieces, 3 products (default), 6 = bf16 pieces, 6 products, "
                          "0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance); 1 / 4 = ONE fp16 / bf16 piece, one product "
                          "(mixed precision: not the reference's arithmetic, not a headline)")
-    ap.add_argument("--head-single-stream", action="store_true",
-                    help="A/B switch: the recurrent heads with every launch on one stream (default: everything off the recurrent "
-                         "dependency chain on a side stream, sgg_amd/head.py; bit-identical results)")
+    ap.add_argument("--head-side-stream", action="store_true",
+                    help="A/B switch: everything off the recurrent dependency chain of the heads on a side stream (sgg_amd/head.py; "
+                         "bit-identical results, measured: no gain)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="N > 1: the ranks only meet (process group, one bucket-sized all-reduce through sgg_amd.dp, barrier) and rank 0 "
                          "prints the `rccl` record with value null - the launch path without a workload (CPU rehearsal over gloo)")
@@ -336,7 +336,7 @@ def main():
     CI = args.critic_iters
     reducer = dpmod.GradReducer() if world > 1 else None
     gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer,
-                 overlap_streams=args.overlap_streams, head_side_stream=not args.head_single_stream)
+                 overlap_streams=args.overlap_streams, head_side_stream=args.head_side_stream)
     extra = 2 + (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0) + (args.two_stream_steps + 1)
     total_steps = args.warmup + args.steps
     images, labels, noises, alphas = synth_inputs(B * world, S, V, (total_steps + extra) * (CI + 1), rank, world, dev)

@@ -78,7 +78,7 @@ class GanStep:
     across data-parallel ranks and returns the scale to apply to the gradient (1/world_size)."""
 
     def __init__(self, K, V, S, B, lam=10.0, E=EMBED_DIM, g_state=None, d_state=None, dtype=torch.float32, reducer=None,
-                 G=None, D=None, overlap_streams=False, head_side_stream=True):
+                 G=None, D=None, overlap_streams=False, head_side_stream=False):
         self.K, self.V, self.S, self.B, self.lam = K, V, S, B, float(lam)
         self.G = G if G is not None else Network(K, "G", V, S, B, E, dtype=dtype, state_dict=g_state)
         self.D = D if D is not None else Network(K, "D", V, S, B, E, dtype=dtype, state_dict=d_state)
@@ -103,8 +103,9 @@ class GanStep:
             self.G.trunk.enable_wgrad_overlap(self.side)
             self.D.trunk.enable_wgrad_overlap(self.side)
         # The recurrent heads are chains of short dependent launches; everything off the chain (embedding / decoder products,
-        # every parameter-gradient GEMM) runs on a stream of its own beside it (head.py).  Always on (also in bench.py's serial
-        # schedule): no convolution kernel runs during a head pass, bit-identical results.
+        # every parameter-gradient GEMM) can run on a stream of its own beside it (head.py; bit-identical results).  Measured:
+        # 47.30 / 47.37 ms per step with it against 47.37 / 47.19 without (same box) - the per-step fork / join events cost what
+        # the overlap of 5-15 us kernels returns - so it is OFF by default (bench.py --head-side-stream).
         self.head_side = torch.cuda.Stream(device=dev) if (head_side_stream and dev.type == "cuda") else None
         self.G.head.enable_side_stream(self.head_side)
         self.D.head.enable_side_stream(self.head_side)

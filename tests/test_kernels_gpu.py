@@ -458,7 +458,8 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
         # LayerNorm partial statistics from the halo epilogue
         nts = hip.conv_tile_stats_count((B, H, W, Co), Ci, 3, 1, 1)
         assert nts in ((H * W // 64) * (Co // (64 if Co % 64 == 0 else 32)),
-                       (H * W // 64) * (Co // (64 if Co % 128 == 0 else 32)))        # (per 64 columns on the 128-column tiling, per 32 otherwise; first form: -DSGG_HALO_N64_NB2=0 builds)
+                       (H * W // 64) * (Co // (64 if Co % 128 == 0 else 32)),        # (per 64 columns on the 128-column tiling, per 32 otherwise; first form: -DSGG_HALO_N64_NB2=0 builds)
+                       (H * W // 64) * (Co // 32))                                  # (-DSGG_HALO_N128_WB2=1 builds: a wave owns two blocks x 32 columns)
         ts = torch.full((B, nts, 4), float("nan"), device="cuda")
         y2 = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y2, 1, ws_f, tile_stats=ts, w_split_layout=1)
