@@ -42,6 +42,9 @@ int sgg_s2d_applicable(int KH, int KW, int stride, int Hi, int Wi, int Cin, int 
 // columns covered by one (count, mean, M2) partial of the halo kernel for N output channels
 int sgg_halo_stats_cols(int N);
 void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st);
+// producer / consumer form for 128-column tiles in the two-piece modes (conv_halo_pc.hip); sgg_halo_launch dispatches to it
+int sgg_halo_pc_applicable(const HaloParams& p, int precision);
+void sgg_halo_pc_launch(const HaloParams& p, int precision, hipStream_t st);
 
 // ---- halo-resident 3x3 stride-1 wgrad (conv_wgrad_halo.hip) ---------------------------------------------------
 struct WgradHaloPlan {

@@ -630,6 +630,10 @@ int sgg_halo_stats_cols(int N) {
 }
 
 void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
+  if (sgg_halo_pc_applicable(p_, precision)) {       // 128-column tiles, two-piece modes: producer / consumer workgroups
+    sgg_halo_pc_launch(p_, precision, st);
+    return;
+  }
   HaloParams p = p_;
   const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);   // (the LN prologue exists in the two-piece modes only: callers check)
 #define SGG_HALO(NB, BN, WGM, WGN, PF, WB)                                                                   \

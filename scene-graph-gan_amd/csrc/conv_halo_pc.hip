@@ -1,0 +1,479 @@
+// Producer / consumer form of the halo-resident 3x3 / stride-1 convolution (gfx950), 128-column tiles, the two-piece 16-bit modes:
+//   tf.layers.conv2d(kernel_size=3, strides=1, padding="same")   reference: architectures/generator_with_attention.py:31-57
+// (conv2_3, conv2_4, conv3_1, conv3_2 and their Conv2DBackpropInput, train.py:265-266).
+//
+// conv_halo.hip runs two 4-wave workgroups per CU, every wave fetching, splitting, multiplying and storing for itself.  Its ablation
+// builds (profiles/r03_halo_ablation*.log) put 10 % of the kernel on the output stores - not their count, their completion: vmcnt
+// counts loads and stores in order, so the first wait for a weight fragment behind a tile's stores is a wait for the stores -,
+// 10 % on the per-wave weight-fragment loads (8 KiB per wave and tap through the CU's 64 B/clk vector-memory return path, the
+// same bytes in every wave of a column half) and 8.5 % on the patch staging.  Here ONE 8-wave workgroup owns the CU:
+//   * waves 0-3, the CONSUMERS (2 blocks x 2 column halves as before, 64 pixels x 64 columns each), issue nothing but LDS reads,
+//     MFMAs and - never waited for - the output stores: no vector-memory load, hence no vmcnt wait, anywhere in their loop;
+//   * waves 4-7, the PRODUCERS, own the vector-memory queue: the patch of the next 32-channel chunk (load, f32 -> 2 x fp16 split or
+//     the LayerNorm + ELU prologue, LDS write) and the weight fragments of the next taps, which go L2 -> LDS by LDS-DMA
+//     (buffer_load ... lds, no VGPRs, no VALU) into a ring of four 16-KiB tap slots shared by the four consumers: the L1 traffic of
+//     the weight operand halves, the consumers read it at LDS bandwidth.
+// One raw s_barrier per tap (24 MFMAs per consumer) is the only synchronisation: behind barrier g the producers guarantee that the
+// fragments of tap g+1 (and, at a chunk's last tap, the next patch) have landed, the consumers that they no longer read slot g.
+// Both roles run the SAME loop nest (tile, chunk, nine statically unrolled taps) with exactly one barrier per tap.
+// LDS: 2 patch buffers (61,440 B) + ring (65,536 B) + LayerNorm parameters (4 KB) of the 160 KB a gfx950 workgroup may use.
+#include "split16.h"
+#include "conv_halo.h"
+#include <type_traits>
+
+#define PC_PITCH 12
+#define PC_BLKB (10 * PC_PITCH * 64)      // bytes of one plane of one block's patch
+#define PC_NB 2
+#define PC_PLANEB (PC_NB * PC_BLKB)
+#define PC_P 2
+#define PC_PATCHB (PC_P * PC_PLANEB)      // one patch buffer
+#define PC_SLOTB 16384                    // one tap of weight fragments for 128 columns: [n-tile 4][k-step 2][plane 2][lane 64] x 16 B
+#define PC_D 4                            // ring slots: the DMA of tap g + 4 is issued behind barrier g and must have landed by barrier g + 3
+#define PC_ITEMS (PC_NB * 400)
+#ifndef PC_INTERLEAVE
+#define PC_INTERLEAVE 1
+#endif
+#define PC_NPASS 4                        // 800 (block, patch pixel, 8-channel group) items over the 256 producer threads
+
+__device__ __forceinline__ int pc_sw(int ry, int rx) { return ((rx >> 2) & 1) | ((ry & 1) << 1); }
+
+typedef __attribute__((address_space(3))) void* pc_lds_ptr;
+
+template <bool HALF, bool LNP>
+__global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PC_PATCHB + PC_D * PC_SLOTB];
+  __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 1024 : 4];      // gamma[0..511], beta at +512 (C <= 512: host check)
+  unsigned char* const ring = lds + 2 * PC_PATCHB;
+
+  // ---- persistent workgroup: as conv_halo3_kernel (XCD k owns a contiguous eighth of the M-tiles, its workgroups walk it interleaved)
+  const int ntiles_n = p.N / 128;
+  const int mtiles = (p.nblk + PC_NB - 1) / PC_NB;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nt = jx % ntiles_n;
+  const int tstride = p.gx / ntiles_n;
+  const int mt_begin = (int)(((long long)xcd * mtiles) >> 3) + jx / ntiles_n;
+  const int mt_end = (int)(((long long)(xcd + 1) * mtiles) >> 3);
+  if (mt_begin >= mt_end) return;             // (whole workgroup: no barrier is ever executed by anyone)
+  const int n0 = nt * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int nch = p.C >> 5;
+  const int adv_rows = (tstride * PC_NB) / p.bw, adv_cols = (tstride * PC_NB) % p.bw;   // block advance between this workgroup's tiles
+  int ea = 0, eb = 0;
+  if constexpr (HALF) {
+    ea = scale_exp_from_amax(*p.amax_src);
+    eb = scale_exp_from_amax(*p.amax_w);
+  }
+
+  if (producer) {
+    // =================================================================================================================
+    // PRODUCERS (waves 4-7, pt = 0 .. 255)
+    // =================================================================================================================
+    const int pt = tid - 256, pw = wave - 4;
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
+    const float sa = ldexpf(1.f, ea);
+    if constexpr (LNP) {
+      for (int c = pt; c < p.ln_nc; c += 256) {
+        lnp_s[c] = p.ln_gamma[c];
+        lnp_s[512 + c] = p.ln_beta[c];
+      }
+    }
+    // ---- staging plan (static per thread): item -> offset relative to its block's patch origin, border bits, LDS offset ----
+    unsigned it_rel[PC_NPASS];
+    int it_meta[PC_NPASS];      // bits 0..19 LDS byte offset inside a plane, 20..23 border bits, 24 block, 26..27 channel group, 28 valid
+#pragma unroll
+    for (int j = 0; j < PC_NPASS; ++j) {
+      const int it = pt + 256 * j;
+      const int blk = it / 400, r = it % 400;
+      const int px = r >> 2, ch8 = r & 3;
+      const int ry = px / 10, rx = px % 10;
+      it_rel[j] = (unsigned)((ry * p.in_rs + rx * p.in_ps + ch8 * 8) * 4);
+      const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
+      it_meta[j] = (blk * PC_BLKB + (ry * PC_PITCH + rx) * 64 + ((ch8 ^ pc_sw(ry, rx)) << 4)) | (bits << 20) | ((blk & 1) << 24) |
+                   (ch8 << 26) | ((it < PC_ITEMS) << 28);
+    }
+    float ld_mu[PC_NB], ld_rs[PC_NB];
+    int ld_cc = 0, ld_bad = 0;
+    int s_grow[PC_NB], s_by[PC_NB], s_bx[PC_NB];
+#pragma unroll
+    for (int j = 0; j < PC_NB; ++j) {
+      const int beta = mt_begin * PC_NB + j;
+      s_grow[j] = beta / p.bw;
+      s_bx[j] = beta % p.bw;
+      s_by[j] = s_grow[j] % p.bh;
+    }
+    int s_tile = mt_begin, s_cc = 0;
+    f32x4 pre[PC_NPASS][2];
+    // issue the global loads of the next (tile, chunk) patch in flat order; past the last tile: out-of-range offsets (zeros)
+    auto stage_load = [&]() __attribute__((always_inline)) {
+      unsigned base[PC_NB];
+      int bbits[PC_NB];
+#pragma unroll
+      for (int j = 0; j < PC_NB; ++j) {
+        const bool dead = (s_tile >= mt_end) | (s_tile * PC_NB + j >= p.nblk);
+        base[j] = (unsigned)(((s_grow[j] * 8 - 1) * p.in_rs + (s_bx[j] * 8 - 1) * p.in_ps + (s_cc >> 1) * p.in_cA + (s_cc & 1) * p.in_cB) * 4);
+        bbits[j] = dead ? 15 : ((s_by[j] == 0) | ((s_by[j] == p.bh - 1) << 1) | ((s_bx[j] == 0) << 2) | ((s_bx[j] == p.bw - 1) << 3));
+        if (dead) base[j] = SGG_OOB;
+      }
+      if constexpr (LNP) {
+        ld_cc = s_cc;
+        ld_bad = 0;
+#pragma unroll
+        for (int j = 0; j < PC_NB; ++j) {
+          int b = s_grow[j] / p.bh;
+          b = b < p.B ? b : p.B - 1;
+          ld_mu[j] = p.ln_stats[2 * b];
+          ld_rs[j] = p.ln_stats[2 * b + 1];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PC_NPASS; ++j) {
+        const int blk = (it_meta[j] >> 24) & 1;
+        const unsigned b0 = blk ? base[1] : base[0];
+        const int bb = blk ? bbits[1] : bbits[0];
+        const bool bad = !((it_meta[j] >> 28) & 1) | ((((it_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
+        const unsigned off = bad ? SGG_OOB : b0 + it_rel[j];
+        if constexpr (LNP) ld_bad |= (int)bad << j;
+        pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
+        pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
+      }
+      if (++s_cc == nch) {        // advance to this workgroup's next tile
+        s_cc = 0;
+        s_tile += tstride;
+#pragma unroll
+        for (int j = 0; j < PC_NB; ++j) {
+          s_bx[j] += adv_cols;
+          s_grow[j] += adv_rows;
+          s_by[j] += adv_rows;
+          if (s_bx[j] >= p.bw) {
+            s_bx[j] -= p.bw;
+            ++s_grow[j];
+            ++s_by[j];
+          }
+          while (s_by[j] >= p.bh) s_by[j] -= p.bh;
+        }
+      }
+    };
+    // split (or LayerNorm + ELU, then split) pass j of the patch in flight and write it into patch buffer `dst`
+    auto stage_write_pass = [&](auto j_c, unsigned char* dst) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_c)::value;
+      if constexpr (LNP) {
+        const int blk = (it_meta[j] >> 24) & 1;
+        const float mu = blk ? ld_mu[1] : ld_mu[0], rs = blk ? ld_rs[1] : ld_rs[0];
+        const int cb = ((ld_cc * 32) & (p.ln_nc - 1)) + ((it_meta[j] >> 26) & 3) * 8;
+        ln_elu8(pre[j][0], pre[j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad >> j) & 1);
+      }
+      u32x4 pl[PC_P];
+      split8<PC_P, HALF>(pre[j][0], pre[j][1], sa, pl);
+      // (passes 0 .. 2 cover items 0 .. 767: always valid; the last pass holds 32 items)
+      if (j < PC_NPASS - 1 || ((it_meta[j] >> 28) & 1)) {
+#pragma unroll
+        for (int pp = 0; pp < PC_P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PC_PLANEB + (it_meta[j] & 0xfffff)) = pl[pp];
+      }
+    };
+    // ---- weight fragments: tap (dcc, dtap) of the stream -> ring slot; this wave moves pieces 4 pw .. 4 pw + 3 of the 16 1-KiB pieces
+    const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
+    const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * 4096u + (unsigned)lane * 16u;
+    int d_cc = 0, d_tap = 0, d_slot = 0;
+    auto dma_issue = [&]() __attribute__((always_inline)) {
+      const unsigned base = (unsigned)(d_tap * nch + d_cc) * w_slab + w_lane;
+      unsigned char* dst = ring + d_slot * PC_SLOTB + pw * 4096;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (pc_lds_ptr)(dst + q * 1024), 16, base + (unsigned)(q * 1024), 0, 0, 0);
+      if (++d_tap == 9) {
+        d_tap = 0;
+        if (++d_cc == nch) d_cc = 0;
+      }
+      d_slot = (d_slot + 1) & (PC_D - 1);
+    };
+
+    // ---- prologue: the first PC_D taps of weights, the first patch ---------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < PC_D; ++k) dma_issue();
+    int cur = 0;                                // patch buffer the consumers read in the current chunk
+    if constexpr (LNP) {
+      // lnp_s is filled by all 256 producer threads and read by all of them: one extra barrier (matched by the consumers)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    stage_load();
+    stage_write_pass(std::integral_constant<int, 0>{}, lds);
+    stage_write_pass(std::integral_constant<int, 1>{}, lds);
+    stage_write_pass(std::integral_constant<int, 2>{}, lds);
+    stage_write_pass(std::integral_constant<int, 3>{}, lds);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 and the fragments of taps 0 .. 3 are in LDS
+
+    // one tap of a chunk: T = 0 .. 8
+    auto tap = [&](auto t_c) __attribute__((always_inline)) {
+      constexpr int T = decltype(t_c)::value;
+      // the patch of the NEXT chunk goes into the buffer the consumers do not read: loads at tap 0, one write pass at taps 4 .. 7
+      // (timing-only ablation builds, wrong results: -DPC_ABL_NOSTAGE no patch staging after the first, -DPC_ABL_NODMA no weight DMA
+      //  after the prologue's, -DPC_ABL_NOEPI no output stores / statistics)
+#ifndef PC_ABL_NOSTAGE
+      if constexpr (T == 0) stage_load();
+      if constexpr (T >= 4 && T <= 7) stage_write_pass(std::integral_constant<int, T - 4>{}, lds + (cur ^ 1) * PC_PATCHB);
+#endif
+      // fragments of tap g + 1 (issued behind barrier g - 3) must have landed.  Younger than them in this wave's vmcnt queue: the
+      // DMAs of taps g + 2, g + 3 (8 instructions) and - at taps 0 .. 2 only, later the patch loads are older - the 8 patch loads
+      if constexpr (T <= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if constexpr (T == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next patch is written
+      __builtin_amdgcn_s_barrier();             // barrier g
+#ifndef PC_ABL_NODMA
+      dma_issue();                              // tap g + 4 into slot g % 4 (the consumers have finished reading tap g)
+#endif
+    };
+    for (int tile = mt_begin; tile < mt_end; tile += tstride) {
+      for (int cc = 0; cc < nch; ++cc) {
+        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        cur ^= 1;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last DMAs target this workgroup's LDS: they must not outlive it)
+    return;
+  }
+
+  // ===================================================================================================================
+  // CONSUMERS (waves 0-3): block wblk = wave >> 1, column half wn0 = (wave & 1) * 64
+  // ===================================================================================================================
+  constexpr int TM = 2, TN = 2;
+  const int wblk = wave >> 1, wn0 = (wave & 1) * 64;
+  const int i = lane & 31, h = lane >> 5;
+  const int pyl = i >> 3, pxl = i & 7;
+  f32x16 acc[TM][TN];
+  acc_zero<TM, TN>(acc);
+  u32x4 a[2][TM][2][PC_P], rb[2][TN][2][PC_P];
+  int cur = 0, slot = 0;       // patch buffer / ring slot of the tap whose operands are read NEXT
+
+  // operands of one tap -> register set `buf`: A from the resident patch (shifted slots), B from the ring slot.  The addresses are
+  // computed BEFORE the tap's barrier (addr_ops: ~16 VALU in the shadow of the k-step-0 MFMAs), the reads issued behind it.
+  struct OpAddr {
+    const unsigned char* row[TM];
+    int hs[TM];
+    const unsigned char* bw;
+  };
+  auto addr_ops = [&](int tp, int patch_buf, int ring_slot) __attribute__((always_inline)) {
+    OpAddr o;
+    const int kh = tp / 3, kw = tp % 3;
+    const int dyy = p.flip ? 2 - kh : kh, dxx = p.flip ? 2 - kw : kw;
+    int pyv = pyl, pxv = pxl;
+    asm volatile("" : "+v"(pyv), "+v"(pxv));       // (keeps the per-tap addresses out of the loop-invariant hoisting, conv_halo.hip)
+    const unsigned char* patch_w = lds + patch_buf * PC_PATCHB + wblk * PC_BLKB;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int ry = tm * 4 + pyv + dyy, rx = pxv + dxx;
+      o.row[tm] = patch_w + (ry * PC_PITCH + rx) * 64;
+      o.hs[tm] = pc_sw(ry, rx);
+    }
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    o.bw = ring + ring_slot * PC_SLOTB + (wn0 >> 5) * 4096 + lv * 16;
+    return o;
+  };
+  auto read_ops = [&](auto buf_c, const OpAddr& o) __attribute__((always_inline)) {
+    constexpr int buf = decltype(buf_c)::value;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pp = 0; pp < PC_P; ++pp)
+          a[buf][tm][ks][pp] = *reinterpret_cast<const u32x4*>(o.row[tm] + pp * PC_PLANEB + (((2 * ks + h) ^ o.hs[tm]) << 4));
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pp = 0; pp < PC_P; ++pp)
+          rb[buf][tn][ks][pp] = *reinterpret_cast<const u32x4*>(o.bw + tn * 4096 + ks * 2048 + pp * 1024);
+  };
+  auto mma_kstep = [&](auto par_c, auto ks_c) __attribute__((always_inline)) {
+    constexpr int par = decltype(par_c)::value, ks = decltype(ks_c)::value;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        f32x16 d = acc[tm][tn];
+        d = mfma16<HALF>(a[par][tm][ks][1], rb[par][tn][ks][0], d);
+        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][1], d);
+        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][0], d);
+        acc[tm][tn] = d;
+      }
+  };
+  // one tap: [addresses of the next tap's operands | MFMAs of k-step 0]  barrier g  [16 LDS reads | MFMAs of k-step 1].
+  // One MFMA wave per SIMD: nothing else feeds the matrix pipe while this wave issues other instructions, so the address arithmetic
+  // is spread over the MFMAs of k-step 0 and the reads over those of k-step 1 (which use the OTHER register set): per MFMA two reads
+  // or a few VALU instructions fit into the 24 cycles it leaves the issue port free.
+  auto tap = [&](auto par_c, auto t_c) __attribute__((always_inline)) {
+    constexpr int par = decltype(par_c)::value, T = decltype(t_c)::value;
+    SGG_PRIO_HI();
+    const int nslot = (slot + 1) & (PC_D - 1), ncur = T == 8 ? cur ^ 1 : cur;
+    const OpAddr o = addr_ops(T == 8 ? 0 : T + 1, ncur, nslot);
+    mma_kstep(par_c, std::integral_constant<int, 0>{});
+#if PC_INTERLEAVE
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       // VALU (addresses)
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();               // barrier g: tap g + 1 (and, at T == 8, the next patch) is in LDS
+    slot = nslot;
+    cur = ncur;
+    read_ops(std::integral_constant<int, par ^ 1>{}, o);
+#if PC_INTERLEAVE
+    mma_kstep(par_c, std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#else
+    __builtin_amdgcn_sched_barrier(0);
+    mma_kstep(par_c, std::integral_constant<int, 1>{});
+#endif
+    SGG_PRIO_LO();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto chunk = [&](auto par0_c) __attribute__((always_inline)) {
+    constexpr int par0 = decltype(par0_c)::value;
+#define PC_TAP(T) tap(std::integral_constant<int, (par0 + T) & 1>{}, std::integral_constant<int, T>{})
+    PC_TAP(0); PC_TAP(1); PC_TAP(2); PC_TAP(3); PC_TAP(4); PC_TAP(5); PC_TAP(6); PC_TAP(7); PC_TAP(8);
+#undef PC_TAP
+  };
+
+  // ---- output addressing (as conv_halo3_kernel with 16-byte stores) ------------------------------------------------------------
+  int o_grow, o_bx;
+  {
+    const int beta = mt_begin * PC_NB + wblk;
+    o_grow = beta / p.bw;
+    o_bx = beta % p.bw;
+  }
+  const unsigned o_lane_b = (unsigned)(((4 * h + (lane & 3)) * p.out_ps) + ((lane & 31) >> 2) * 4) * 4u;
+  int o_goff[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int gi = ((n0 + wn0) >> 5) + tn;
+    o_goff[tn] = (gi >> 1) * p.out_nA + (gi & 1) * p.out_nB;
+  }
+  const float us_a = ldexpf(1.f, -ea), us_b = ldexpf(1.f, -eb);
+  float bias_v[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) bias_v[tn] = p.bias ? p.bias[n0 + wn0 + tn * 32 + acc_col(lane)] : 0.f;
+  const int wn = p.out_rs;
+  constexpr int WN = 64;
+
+  auto epilogue = [&](int tile) __attribute__((always_inline)) {
+    const int beta = tile * PC_NB + wblk;
+    const bool live = beta < p.nblk;
+    const char* ob = reinterpret_cast<const char*>(p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.out_ps);
+    float lsum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = HALF ? fmaf(acc[tm][tn][r] * us_a, us_b, bias_v[tn]) : acc[tm][tn][r] + bias_v[tn];
+          acc[tm][tn][r] = v;
+          lsum += v;
+        }
+#ifdef PC_ABL_NOEPI
+    if (p.B < 0) {
+#else
+    if (live) {
+#endif
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v0 = acc[tm][tn][4 * q], v1 = acc[tm][tn][4 * q + 1], v2 = acc[tm][tn][4 * q + 2], v3 = acc[tm][tn][4 * q + 3];
+            sgg_quad_transpose4(v0, v1, v2, v3, lane);
+            const size_t so = ((size_t)(tm * 4 + q) * wn + o_goff[tn]) * sizeof(float);
+            sgg_out_store4(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), f32x4{v0, v1, v2, v3});
+          }
+    }
+#ifdef PC_ABL_NOEPI
+    if (p.B < 0) {
+#else
+    if (p.tile_stats) {
+#endif
+      const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));
+      float q = 0.f, dm = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[tm][tn][r] - mean_w;
+            q += d * d;
+            dm = fmaxf(dm, fabsf(d));
+          }
+      q = wave_sum(q);
+      dm = wave_max(dm);
+      if (lane == 0 && live) {
+        float* o = p.tile_stats + ((size_t)beta * (p.N / WN) + (n0 + wn0) / WN) * SGG_TS;
+        o[0] = (float)(64 * WN);
+        o[1] = mean_w;
+        o[2] = q;
+        o[3] = dm;
+      }
+    }
+    acc_zero<TM, TN>(acc);
+    o_bx += adv_cols;
+    o_grow += adv_rows;
+    if (o_bx >= p.bw) { o_bx -= p.bw; ++o_grow; }
+  };
+
+  if constexpr (LNP) __builtin_amdgcn_s_barrier();      // (matches the producers' barrier behind their lnp_s fill)
+  __builtin_amdgcn_s_barrier();                          // barrier "-1"
+  read_ops(std::integral_constant<int, 0>{}, addr_ops(0, 0, 0));         // tap 0: patch buffer 0, ring slot 0
+  // (C % 64 == 0: an even number of chunks; the register-set parity flips once per chunk of nine taps)
+  for (int tile = mt_begin; tile < mt_end; tile += tstride) {
+    for (int cc = 0; cc < nch; cc += 2) {
+      chunk(std::integral_constant<int, 0>{});
+      chunk(std::integral_constant<int, 1>{});
+    }
+    epilogue(tile);
+  }
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------------------
+// 1 if the producer / consumer kernel serves this launch: the two-piece modes (precision 2 / 3), 128-column tiles, an even number of
+// 32-channel chunks (C % 64 == 0).  -DSGG_HALO_PC=0 builds never use it.
+#ifndef SGG_HALO_PC
+#define SGG_HALO_PC 1
+#endif
+int sgg_halo_pc_applicable(const HaloParams& p, int precision) {
+  return SGG_HALO_PC && (precision == 2 || precision == 3) && p.N % 128 == 0 && p.C % 64 == 0 && p.C <= 512;
+}
+
+void sgg_halo_pc_launch(const HaloParams& p_, int precision, hipStream_t st) {
+  HaloParams p = p_;
+  const int mtiles = sgg_cdiv(p.nblk, PC_NB), ntn = p.N / 128;
+  int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       // (tile, n-tile) pairs an XCD owns
+  int gx = per_xcd < 32 ? per_xcd : 32;          // one workgroup on each of its 32 CUs
+  gx = sgg_cdiv(gx, ntn) * ntn;
+  p.gx = gx;
+  const dim3 grid((unsigned)(8 * gx)), blk(512);
+  const bool half = precision == 2;
+  if (p.ln_stats) {
+    if (half) hipLaunchKernelGGL((conv_halo3_pc_kernel<true, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((conv_halo3_pc_kernel<false, true>), grid, blk, 0, st, p);
+  } else {
+    if (half) hipLaunchKernelGGL((conv_halo3_pc_kernel<true, false>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((conv_halo3_pc_kernel<false, false>), grid, blk, 0, st, p);
+  }
+}
