@@ -59,7 +59,14 @@ int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; ze
  * returns 3 - the convolution runs on the halo-resident kernel as a 3x3 stride-1 convolution over the space-to-depth view of x
  * (x[2a + qy][2c + qx][ci] = channel (qy, qx, ci) of pixel (a, c); no copy, strides only) with the 9-tap kernel
  * [3][3][4 * Cin][Cout] of sgg_conv_s2d_weights (11 of its 36 (tap, parity) slots are zero); weights in fragment order with
- * taps = 9 (forward: the HWOI transpose of that kernel, N = Cout, C = 4 * Cin; dgrad: the kernel itself, N = 4 * Cin, C = Cout). */
+ * taps = 9 (forward: the HWOI transpose of that kernel, N = Cout, C = 4 * Cin; dgrad: the kernel itself, N = 4 * Cin, C = Cout).
+ * Producer / consumer kernel for the 3x3 stride-1 layers with 128-column tiles (generator_with_attention.py:44-57: conv2_3,
+ * conv2_4, conv3_1, conv3_2 forward; conv2_4, conv3_1, conv3_2 dgrad): where a layout-1 layer also has Cout % 128 == 0 and
+ * Cin % 64 == 0 in precision 2 / 3, sgg_conv_wsplit_layout returns 4 instead - one 8-wave workgroup per CU (4 MFMA waves on
+ * v_mfma_f32_16x16x32_*, 2 weight-DMA waves, 2 patch-staging waves; csrc/conv_halo_pc.hip); the pre-split weights are then the
+ * fragments of THAT MFMA shape (sgg_conv_split_weights_frag16) and w_split_layout = 4 is passed to sgg_conv2d_nhwc_fwd / _dgrad.
+ * Same arithmetic as layout 1 (same pieces, same three products per f32 product, f32 accumulation; the order of the sum over the
+ * 32 channels of a chunk differs). */
 int sgg_conv_s2d_weights(const float* w5 /* [5][5][Cin][Cout] */, float* w3 /* [3][3][4*Cin][Cout] */, int Cin, int Cout, void* stream);
 /* All of the above for every layer of one encoder after an optimiser step, in three launches (the per-layer entry points are
  * ~45 five-microsecond launches per network): w_hwoi = the HWOI transpose; *amax = max|w| (precision 1 / 2; may be NULL
@@ -81,6 +88,7 @@ int sgg_conv_prepare_weights(const sgg_conv_weight_desc* layers, int n_layers, i
  * arguments (w_split_layout here, `algo` of sgg_conv2d_nhwc_wgrad). */
 int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);
 int sgg_conv_split_weights_frag(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
+int sgg_conv_split_weights_frag16(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
                         const float* amax_x, const float* amax_w, float* tile_stats, const float* ln_stats, const float* ln_gamma,

@@ -789,7 +789,7 @@ extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout,
                                               int w_split_layout) {
   if (Cin == 3) return (KH == 3 && KW == 3 && stride == 1 && Cout == 32) ? sgg_cdiv(Ho, 8) * sgg_cdiv(Wo, 32) : 0;   // any precision
   if (precision == 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
-  if (w_split_layout == 1) {
+  if (w_split_layout == 1 || w_split_layout == 4) {
     if (!sgg_halo_applicable(KH, KW, stride, Ho, Wo, Cin, Cout, precision)) return 0;
     return (Ho * Wo / 64) * (Cout / sgg_halo_stats_cols(Cout));
   }
@@ -813,8 +813,8 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
                                    int precision, int w_split_layout, const float* amax_x, const float* amax_w, float* tile_stats,
                                    const float* ln_stats, const float* ln_gamma, const float* ln_beta, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
-  SGG_CHECK_ARG(!ln_stats || (w_split_layout >= 1 && w_split_layout <= 3 && ln_gamma && ln_beta && Cin <= 512),
-                "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1, 2 or 3 (resident kernels), gamma, beta and Cin <= 512");
+  SGG_CHECK_ARG(!ln_stats || (w_split_layout >= 1 && w_split_layout <= 4 && ln_gamma && ln_beta && Cin <= 512),
+                "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1 .. 4 (resident kernels), gamma, beta and Cin <= 512");
   SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 1, 2, 3, 4 or 6");
   SGG_CHECK_ARG(!sgg_prec_half(precision) || Cin == 3 || (amax_x && amax_w), "sgg_conv2d_nhwc_fwd: precision 1 / 2 need the amax words");
   SGG_CHECK_ARG(!ln_stats || !sgg_prec_one(precision), "sgg_conv2d_nhwc_fwd: the LN prologue exists in the two-piece modes (2, 3) only");
@@ -834,9 +834,11 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     return SGG_OK;
   }
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_fwd: Cin and Cout must be multiples of 32 (or Cin == 3)");
-  if (w_split_layout == 1) {        // halo-resident 3x3 stride-1 kernel, weights in MFMA fragment order
+  if (w_split_layout == 1 || w_split_layout == 4) {        // halo-resident 3x3 stride-1 kernels, weights in MFMA fragment order
     SGG_CHECK_ARG(w_split && sgg_halo_applicable(KH, KW, stride, Hi, Wi, Cin, Cout, precision) && pad_t == 1 && pad_l == 1,
-                  "sgg_conv2d_nhwc_fwd: w_split_layout 1 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
+                  "sgg_conv2d_nhwc_fwd: w_split_layout 1 / 4 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
+    SGG_CHECK_ARG(w_split_layout != 4 || sgg_halo_pc_applicable(Cin, Cout, precision),
+                  "sgg_conv2d_nhwc_fwd: w_split_layout 4 needs Cout %% 128 == 0, Cin %% 64 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
     HaloParams h;
     h.src = x; h.wfrag = w_split; h.bias = bias; h.out = y; h.amax_src = amax_x; h.amax_w = amax_w; h.tile_stats = tile_stats;
     h.ln_stats = ln_stats; h.ln_gamma = ln_gamma; h.ln_beta = ln_beta;
@@ -844,6 +846,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     h.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
     sgg_halo_dense_strides(h);
+    h.frag16 = w_split_layout == 4;
     SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(halo)");
@@ -917,10 +920,12 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
   SGG_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "sgg_conv2d_nhwc_dgrad: Cin and Cout must be multiples of 32");
   SGG_CHECK_ARG((long long)B * Hi * Wi * Cin < (1LL << 31) && (long long)B * Ho * Wo * Cout < (1LL << 31),
                 "sgg_conv2d_nhwc_dgrad: tensor exceeds 2^31 elements");
-  if (w_split_layout == 1) {        // halo-resident 3x3 stride-1 kernel: dx = correlation of dy with the mirrored taps
+  if (w_split_layout == 1 || w_split_layout == 4) {        // halo-resident 3x3 stride-1 kernels: dx = correlation of dy with the mirrored taps
     SGG_CHECK_ARG(w_split && sgg_halo_applicable(KH, KW, stride, Hi, Wi, Cout, Cin, precision) && pad_t == 1 && pad_l == 1 &&
                       Ho == Hi && Wo == Wi,
-                  "sgg_conv2d_nhwc_dgrad: w_split_layout 1 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
+                  "sgg_conv2d_nhwc_dgrad: w_split_layout 1 / 4 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
+    SGG_CHECK_ARG(w_split_layout != 4 || sgg_halo_pc_applicable(Cout, Cin, precision),
+                  "sgg_conv2d_nhwc_dgrad: w_split_layout 4 needs Cin %% 128 == 0, Cout %% 64 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
     SGG_CHECK_ARG((size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_dgrad: dy exceeds 2 GiB");
     HaloParams h;
     h.src = dy; h.wfrag = w_split; h.bias = nullptr; h.out = dx; h.amax_src = amax_dy; h.amax_w = amax_w; h.tile_stats = nullptr;
@@ -929,6 +934,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     h.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
     sgg_halo_dense_strides(h);
+    h.frag16 = w_split_layout == 4;
     sgg_halo_launch(h, precision, (hipStream_t)stream);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(halo)");
     return SGG_OK;

@@ -29,11 +29,13 @@ struct HaloParams {
   int in_rs, in_ps, in_cA, in_cB;
   int out_rs, out_ps, out_nA, out_nB;
   int ln_nc;              // LN prologue: real channels of the source (a power of two: C, or 32 for the space-to-depth view)
+  int frag16;             // 1: wfrag holds the fragments of the K = 32 MFMA shape (w_split_layout 4): the producer / consumer kernel
 };
 inline void sgg_halo_dense_strides(HaloParams& h) {
   h.in_rs = h.W * h.C; h.in_ps = h.C; h.in_cA = 64; h.in_cB = 32;
   h.out_rs = h.W * h.N; h.out_ps = h.N; h.out_nA = 64; h.out_nB = 32;
   h.ln_nc = h.C;
+  h.frag16 = 0;
 }
 
 // 1 if the halo kernel serves a 3x3 / stride-1 convolution over an H x W grid in this precision
@@ -42,8 +44,9 @@ int sgg_s2d_applicable(int KH, int KW, int stride, int Hi, int Wi, int Cin, int 
 // columns covered by one (count, mean, M2) partial of the halo kernel for N output channels
 int sgg_halo_stats_cols(int N);
 void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st);
-// producer / consumer form for 128-column tiles in the two-piece modes (conv_halo_pc.hip); sgg_halo_launch dispatches to it
-int sgg_halo_pc_applicable(const HaloParams& p, int precision);
+// producer / consumer form for 128-column tiles in the two-piece modes (conv_halo_pc.hip; weights in w_split_layout 4);
+// sgg_halo_launch dispatches to it when HaloParams::frag16 is set
+int sgg_halo_pc_applicable(int C, int N, int precision);
 void sgg_halo_pc_launch(const HaloParams& p, int precision, hipStream_t st);
 
 // ---- halo-resident 3x3 stride-1 wgrad (conv_wgrad_halo.hip) ---------------------------------------------------

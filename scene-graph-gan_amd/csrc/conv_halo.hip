@@ -630,7 +630,7 @@ int sgg_halo_stats_cols(int N) {
 }
 
 void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
-  if (sgg_halo_pc_applicable(p_, precision)) {       // 128-column tiles, two-piece modes: producer / consumer workgroups
+  if (p_.frag16) {       // w_split_layout 4 (128-column tiles, two-piece modes): producer / consumer workgroups, K = 32 MFMA shape
     sgg_halo_pc_launch(p_, precision, st);
     return;
   }
@@ -677,11 +677,49 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
 // (forward input / dgrad output); for the dgrad direction pass (Cin, Cout) swapped, as for layout 1.
 // 3 = 5x5 stride 2 over 32 -> 32 channels as a 3x3 convolution over the space-to-depth view: the 9-tap kernel of
 // sgg_conv_s2d_weights ([3][3][128][32]) in fragment order (forward: its HWOI transpose with N = 32, C = 128; dgrad: N = 128, C = 32).
+// 4 = layout 1's layers that run on the producer / consumer kernel (conv_halo_pc.hip: 128-column tiles, Cin % 64 == 0, precision 2 / 3):
+// the fragments of the K = 32 MFMA shape, sgg_conv_split_weights_frag16.
 extern "C" int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision) {
-  if (sgg_halo_applicable(KH, KW, stride, H, W, Cin, Cout, precision)) return 1;
+  if (sgg_halo_applicable(KH, KW, stride, H, W, Cin, Cout, precision)) return sgg_halo_pc_applicable(Cin, Cout, precision) ? 4 : 1;
   if (sgg_s2_applicable(KH, KW, stride, 1, H, W, Cin, Cout, precision)) return 2;
   if (sgg_s2d_applicable(KH, KW, stride, H, W, Cin, Cout, precision)) return 3;
   return 0;
+}
+
+// f32 [taps][N][C] -> two 16-bit planes in the B-fragment order of v_mfma_f32_16x16x32: [tap][C/32][N/16][plane][lane] x 16 B,
+// lane l of fragment (tap, chunk, n-tile, plane) holds w[tap][n-tile*16 + (l&15)][chunk*32 + 8*(l>>4) .. +8]  (w_split_layout 4)
+template <bool HALF>
+__global__ void split_weights_frag16_kernel(const float* __restrict__ in, u32x4* __restrict__ out, int taps, int N, int C,
+                                            const float* __restrict__ amax) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nch = C >> 5, ntl = N >> 4;
+  if (idx >= (long long)taps * nch * ntl * 64) return;
+  const int lane = (int)(idx & 63);
+  long long r = idx >> 6;
+  const int ntile = (int)(r % ntl); r /= ntl;
+  const int cc = (int)(r % nch);
+  const int tap = (int)(r / nch);
+  const int n = ntile * 16 + (lane & 15), k = cc * 32 + 8 * (lane >> 4);
+  const float* src = in + ((size_t)tap * N + n) * C + k;
+  const float scale = HALF ? ldexpf(1.f, scale_exp_from_amax(*amax)) : 1.f;
+  u32x4 pl[2];
+  split8<2, HALF>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), scale, pl);
+  const size_t o = (((size_t)(tap * nch + cc) * ntl + ntile) * 2) * 64 + lane;
+  out[o] = pl[0];
+  out[o + 64] = pl[1];
+}
+extern "C" int sgg_conv_split_weights_frag16(const float* in, void* out, int taps, int N, int C, int precision, const float* amax,
+                                             void* stream) {
+  SGG_CHECK_ARG(in && out && taps > 0 && N > 0 && C > 0 && N % 16 == 0 && C % 32 == 0 && (precision == 2 || precision == 3) &&
+                    (precision != 2 || amax),
+                "sgg_conv_split_weights_frag16: bad argument");
+  const long long n = (long long)taps * (C / 32) * (N / 16) * 64;
+  const dim3 grid(sgg_cdiv(n, 256)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == 2) hipLaunchKernelGGL(split_weights_frag16_kernel<true>, grid, blk, 0, st, in, (u32x4*)out, taps, N, C, amax);
+  else hipLaunchKernelGGL(split_weights_frag16_kernel<false>, grid, blk, 0, st, in, (u32x4*)out, taps, N, C, amax);
+  SGG_LAUNCH_CHECK("sgg_conv_split_weights_frag16");
+  return SGG_OK;
 }
 
 // in: f32 [taps][N][C] (forward: the HWOI transpose, N = Cout, C = Cin; dgrad: the HWIO kernel, N = Cin, C = Cout)

@@ -9,10 +9,12 @@
 // same bytes in every wave of a column half) and 8.5 % on the patch staging.  Here ONE 8-wave workgroup owns the CU:
 //   * waves 0-3, the CONSUMERS (2 blocks x 2 column halves as before, 64 pixels x 64 columns each), issue nothing but LDS reads,
 //     MFMAs and - never waited for - the output stores: no vector-memory load, hence no vmcnt wait, anywhere in their loop;
-//   * waves 4-7, the PRODUCERS, own the vector-memory queue: the patch of the next 32-channel chunk (load, f32 -> 2 x fp16 split or
-//     the LayerNorm + ELU prologue, LDS write) and the weight fragments of the next taps, which go L2 -> LDS by LDS-DMA
-//     (buffer_load ... lds, no VGPRs, no VALU) into a ring of four 16-KiB tap slots shared by the four consumers: the L1 traffic of
-//     the weight operand halves, the consumers read it at LDS bandwidth.
+//   * waves 4-5, the WEIGHT PRODUCERS, move the weight fragments of the next taps L2 -> LDS by LDS-DMA (buffer_load ... lds, no VGPRs,
+//     no VALU) into a ring of four 16-KiB tap slots shared by the four consumers: the L1 traffic of the weight operand halves, the
+//     consumers read it at LDS bandwidth;
+//   * waves 6-7, the PATCH PRODUCERS, stage the activation patch two 32-channel chunks ahead (load, f32 -> 2 x fp16 split or the
+//     LayerNorm + ELU prologue, LDS write).  Separate waves because vmcnt retires in order: in one queue every wait for a weight
+//     DMA would wait for the (HBM-latency) patch loads issued before it.
 // One raw s_barrier per tap (24 MFMAs per consumer) is the only synchronisation: behind barrier g the producers guarantee that the
 // fragments of tap g+1 (and, at a chunk's last tap, the next patch) have landed, the consumers that they no longer read slot g.
 // Both roles run the SAME loop nest (tile, chunk, nine statically unrolled taps) with exactly one barrier per tap.
@@ -33,9 +35,13 @@
 #ifndef PC_INTERLEAVE
 #define PC_INTERLEAVE 1
 #endif
-#define PC_NPASS 4                        // 800 (block, patch pixel, 8-channel group) items over the 256 producer threads
+#define PC_NPASS 7                        // 800 (block, patch pixel, 8-channel group) items over the 128 patch-producer threads
 
-__device__ __forceinline__ int pc_sw(int ry, int rx) { return ((rx >> 2) & 1) | ((ry & 1) << 1); }
+// XOR swizzle of the 16-byte chunk index inside a pixel's 64-byte row (write and read side).  With the 16x16x32 operand read (16
+// lanes = two patch rows x 8 pixels take one chunk each, four such groups per ds_read_b128) every read of every tap is conflict free
+// with chunk ^= ((rx ^ (ry >> 1)) & 1) | ((ry & 1) << 1)  (brute force over the instruction's lane groups, MI355X_MICROARCH.md LDS;
+// conv_halo.hip's ((rx >> 2) & 1) | ((ry & 1) << 1) is 2-way conflicted on this access pattern).
+__device__ __forceinline__ int pc_sw(int ry, int rx) { return ((rx ^ (ry >> 1)) & 1) | ((ry & 1) << 1); }
 
 typedef __attribute__((address_space(3))) void* pc_lds_ptr;
 
@@ -57,7 +63,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
   const int n0 = nt * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= 4;
   const int nch = p.C >> 5;
   const int adv_rows = (tstride * PC_NB) / p.bw, adv_cols = (tstride * PC_NB) % p.bw;   // block advance between this workgroup's tiles
   int ea = 0, eb = 0;
@@ -66,16 +71,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     eb = scale_exp_from_amax(*p.amax_w);
   }
 
-  if (producer) {
+  if (wave >= 6) {
     // =================================================================================================================
-    // PRODUCERS (waves 4-7, pt = 0 .. 255)
+    // PATCH PRODUCERS (waves 6-7, pt = 0 .. 127): the patch of chunk c + 2 is LOADED at tap 0 of chunk c (two register sets), the
+    // patch of chunk c + 1 is split and WRITTEN at taps 1 .. 7 of chunk c: a load has nine taps to arrive.  (Waves of their own:
+    // vmcnt retires in order, so in one queue with the weight DMAs every wait for a DMA would also wait for the patch loads.)
     // =================================================================================================================
-    const int pt = tid - 256, pw = wave - 4;
+    const int pt = tid - 384;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
     const float sa = ldexpf(1.f, ea);
     if constexpr (LNP) {
-      for (int c = pt; c < p.ln_nc; c += 256) {
+      for (int c = pt; c < p.ln_nc; c += 128) {
         lnp_s[c] = p.ln_gamma[c];
         lnp_s[512 + c] = p.ln_beta[c];
       }
@@ -85,17 +91,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     int it_meta[PC_NPASS];      // bits 0..19 LDS byte offset inside a plane, 20..23 border bits, 24 block, 26..27 channel group, 28 valid
 #pragma unroll
     for (int j = 0; j < PC_NPASS; ++j) {
-      const int it = pt + 256 * j;
-      const int blk = it / 400, r = it % 400;
+      const int it = pt + 128 * j;
+      const int blk = (it / 400) & 1, r = it % 400;
       const int px = r >> 2, ch8 = r & 3;
       const int ry = px / 10, rx = px % 10;
       it_rel[j] = (unsigned)((ry * p.in_rs + rx * p.in_ps + ch8 * 8) * 4);
       const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
-      it_meta[j] = (blk * PC_BLKB + (ry * PC_PITCH + rx) * 64 + ((ch8 ^ pc_sw(ry, rx)) << 4)) | (bits << 20) | ((blk & 1) << 24) |
+      it_meta[j] = (blk * PC_BLKB + (ry * PC_PITCH + rx) * 64 + ((ch8 ^ pc_sw(ry, rx)) << 4)) | (bits << 20) | (blk << 24) |
                    (ch8 << 26) | ((it < PC_ITEMS) << 28);
     }
-    float ld_mu[PC_NB], ld_rs[PC_NB];
-    int ld_cc = 0, ld_bad = 0;
+    float ld_mu[2][PC_NB], ld_rs[2][PC_NB];
+    int ld_cc[2] = {0, 0}, ld_bad[2] = {0, 0};
     int s_grow[PC_NB], s_by[PC_NB], s_bx[PC_NB];
 #pragma unroll
     for (int j = 0; j < PC_NB; ++j) {
@@ -105,9 +111,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       s_by[j] = s_grow[j] % p.bh;
     }
     int s_tile = mt_begin, s_cc = 0;
-    f32x4 pre[PC_NPASS][2];
-    // issue the global loads of the next (tile, chunk) patch in flat order; past the last tile: out-of-range offsets (zeros)
-    auto stage_load = [&]() __attribute__((always_inline)) {
+    f32x4 pre[2][PC_NPASS][2];
+    // issue the global loads of the next (tile, chunk) patch of the stream into register set S; past the last tile: out-of-range offsets (zeros)
+    auto stage_load = [&](auto s_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(s_c)::value;
       unsigned base[PC_NB];
       int bbits[PC_NB];
 #pragma unroll
@@ -118,14 +125,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         if (dead) base[j] = SGG_OOB;
       }
       if constexpr (LNP) {
-        ld_cc = s_cc;
-        ld_bad = 0;
+        ld_cc[S] = s_cc;
+        ld_bad[S] = 0;
 #pragma unroll
         for (int j = 0; j < PC_NB; ++j) {
           int b = s_grow[j] / p.bh;
           b = b < p.B ? b : p.B - 1;
-          ld_mu[j] = p.ln_stats[2 * b];
-          ld_rs[j] = p.ln_stats[2 * b + 1];
+          ld_mu[S][j] = p.ln_stats[2 * b];
+          ld_rs[S][j] = p.ln_stats[2 * b + 1];
         }
       }
 #pragma unroll
@@ -135,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         const int bb = blk ? bbits[1] : bbits[0];
         const bool bad = !((it_meta[j] >> 28) & 1) | ((((it_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
         const unsigned off = bad ? SGG_OOB : b0 + it_rel[j];
-        if constexpr (LNP) ld_bad |= (int)bad << j;
-        pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
-        pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
+        if constexpr (LNP) ld_bad[S] |= (int)bad << j;
+        pre[S][j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
+        pre[S][j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
       }
       if (++s_cc == nch) {        // advance to this workgroup's next tile
         s_cc = 0;
@@ -156,32 +163,83 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         }
       }
     };
-    // split (or LayerNorm + ELU, then split) pass j of the patch in flight and write it into patch buffer `dst`
-    auto stage_write_pass = [&](auto j_c, unsigned char* dst) __attribute__((always_inline)) {
-      constexpr int j = decltype(j_c)::value;
+    // split (or LayerNorm + ELU, then split) pass j of register set S and write it into patch buffer `dst`
+    auto stage_write_pass = [&](auto s_c, auto j_c, unsigned char* dst) __attribute__((always_inline)) {
+      constexpr int S = decltype(s_c)::value, j = decltype(j_c)::value;
       if constexpr (LNP) {
         const int blk = (it_meta[j] >> 24) & 1;
-        const float mu = blk ? ld_mu[1] : ld_mu[0], rs = blk ? ld_rs[1] : ld_rs[0];
-        const int cb = ((ld_cc * 32) & (p.ln_nc - 1)) + ((it_meta[j] >> 26) & 3) * 8;
-        ln_elu8(pre[j][0], pre[j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad >> j) & 1);
+        const float mu = blk ? ld_mu[S][1] : ld_mu[S][0], rs = blk ? ld_rs[S][1] : ld_rs[S][0];
+        const int cb = ((ld_cc[S] * 32) & (p.ln_nc - 1)) + ((it_meta[j] >> 26) & 3) * 8;
+        ln_elu8(pre[S][j][0], pre[S][j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad[S] >> j) & 1);
       }
       u32x4 pl[PC_P];
-      split8<PC_P, HALF>(pre[j][0], pre[j][1], sa, pl);
-      // (passes 0 .. 2 cover items 0 .. 767: always valid; the last pass holds 32 items)
+      split8<PC_P, HALF>(pre[S][j][0], pre[S][j][1], sa, pl);
+      // (passes 0 .. 5 cover items 0 .. 767: always valid; the last pass holds 32 items)
       if (j < PC_NPASS - 1 || ((it_meta[j] >> 28) & 1)) {
 #pragma unroll
         for (int pp = 0; pp < PC_P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PC_PLANEB + (it_meta[j] & 0xfffff)) = pl[pp];
       }
     };
-    // ---- weight fragments: tap (dcc, dtap) of the stream -> ring slot; this wave moves pieces 4 pw .. 4 pw + 3 of the 16 1-KiB pieces
+    auto write_all = [&](auto s_c, unsigned char* dst) __attribute__((always_inline)) {
+      stage_write_pass(s_c, std::integral_constant<int, 0>{}, dst); stage_write_pass(s_c, std::integral_constant<int, 1>{}, dst);
+      stage_write_pass(s_c, std::integral_constant<int, 2>{}, dst); stage_write_pass(s_c, std::integral_constant<int, 3>{}, dst);
+      stage_write_pass(s_c, std::integral_constant<int, 4>{}, dst); stage_write_pass(s_c, std::integral_constant<int, 5>{}, dst);
+      stage_write_pass(s_c, std::integral_constant<int, 6>{}, dst);
+    };
+    int cur = 0;                                // patch buffer the consumers read in the current chunk
+    if constexpr (LNP) {
+      // lnp_s is filled and read by the 128 patch-producer threads: one extra barrier (matched by every other wave)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    stage_load(std::integral_constant<int, 0>{});            // chunk 0
+    write_all(std::integral_constant<int, 0>{}, lds);
+    stage_load(std::integral_constant<int, 1>{});            // chunk 1: in flight across the prologue barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 is in LDS
+
+    // one tap of chunk c (register-set parity S = c & 1): T = 0 .. 8
+    auto tap = [&](auto s_c, auto t_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(s_c)::value, T = decltype(t_c)::value;
+      // (timing-only ablation builds, wrong results: -DPC_ABL_NOSTAGE no patch staging after the first, -DPC_ABL_NODMA no weight DMA
+      //  after the prologue's, -DPC_ABL_NOEPI no output stores / statistics)
+#ifndef PC_ABL_NOSTAGE
+      if constexpr (T == 0) stage_load(s_c);                                    // chunk c + 2 -> set S (chunk c's data left it a chunk ago)
+      if constexpr (T >= 1 && T <= 7)                                           // chunk c + 1 (set S ^ 1) -> the buffer the consumers do not read
+        stage_write_pass(std::integral_constant<int, S ^ 1>{}, std::integral_constant<int, T - 1>{}, lds + (cur ^ 1) * PC_PATCHB);
+#endif
+      if constexpr (T == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next patch is written
+      __builtin_amdgcn_s_barrier();             // barrier g
+    };
+    auto chunk = [&](auto s_c) __attribute__((always_inline)) {
+      tap(s_c, std::integral_constant<int, 0>{}); tap(s_c, std::integral_constant<int, 1>{}); tap(s_c, std::integral_constant<int, 2>{});
+      tap(s_c, std::integral_constant<int, 3>{}); tap(s_c, std::integral_constant<int, 4>{}); tap(s_c, std::integral_constant<int, 5>{});
+      tap(s_c, std::integral_constant<int, 6>{}); tap(s_c, std::integral_constant<int, 7>{}); tap(s_c, std::integral_constant<int, 8>{});
+      cur ^= 1;
+    };
+    for (int tile = mt_begin; tile < mt_end; tile += tstride) {
+      for (int cc = 0; cc < nch; cc += 2) {
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+      }
+    }
+    return;
+  }
+  if (wave >= 4) {
+    // =================================================================================================================
+    // WEIGHT PRODUCERS (waves 4-5): tap (d_cc, d_tap) of the fragment stream -> ring slot by LDS-DMA; this wave moves pieces
+    // 8 dw .. 8 dw + 7 of the tap's sixteen 1-KiB pieces [n-tile][k-step][plane]
+    // =================================================================================================================
+    const int dw = wave - 4;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
     const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
-    const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * 4096u + (unsigned)lane * 16u;
+    const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)dw * 8192u + (unsigned)lane * 16u;
     int d_cc = 0, d_tap = 0, d_slot = 0;
     auto dma_issue = [&]() __attribute__((always_inline)) {
       const unsigned base = (unsigned)(d_tap * nch + d_cc) * w_slab + w_lane;
-      unsigned char* dst = ring + d_slot * PC_SLOTB + pw * 4096;
+      unsigned char* dst = ring + d_slot * PC_SLOTB + dw * 8192;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 8; ++q)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (pc_lds_ptr)(dst + q * 1024), 16, base + (unsigned)(q * 1024), 0, 0, 0);
       if (++d_tap == 9) {
         d_tap = 0;
@@ -189,50 +247,22 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       }
       d_slot = (d_slot + 1) & (PC_D - 1);
     };
-
-    // ---- prologue: the first PC_D taps of weights, the first patch ---------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < PC_D; ++k) dma_issue();
-    int cur = 0;                                // patch buffer the consumers read in the current chunk
-    if constexpr (LNP) {
-      // lnp_s is filled by all 256 producer threads and read by all of them: one extra barrier (matched by the consumers)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    stage_load();
-    stage_write_pass(std::integral_constant<int, 0>{}, lds);
-    stage_write_pass(std::integral_constant<int, 1>{}, lds);
-    stage_write_pass(std::integral_constant<int, 2>{}, lds);
-    stage_write_pass(std::integral_constant<int, 3>{}, lds);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 and the fragments of taps 0 .. 3 are in LDS
-
-    // one tap of a chunk: T = 0 .. 8
-    auto tap = [&](auto t_c) __attribute__((always_inline)) {
-      constexpr int T = decltype(t_c)::value;
-      // the patch of the NEXT chunk goes into the buffer the consumers do not read: loads at tap 0, one write pass at taps 4 .. 7
-      // (timing-only ablation builds, wrong results: -DPC_ABL_NOSTAGE no patch staging after the first, -DPC_ABL_NODMA no weight DMA
-      //  after the prologue's, -DPC_ABL_NOEPI no output stores / statistics)
-#ifndef PC_ABL_NOSTAGE
-      if constexpr (T == 0) stage_load();
-      if constexpr (T >= 4 && T <= 7) stage_write_pass(std::integral_constant<int, T - 4>{}, lds + (cur ^ 1) * PC_PATCHB);
-#endif
-      // fragments of tap g + 1 (issued behind barrier g - 3) must have landed.  Younger than them in this wave's vmcnt queue: the
-      // DMAs of taps g + 2, g + 3 (8 instructions) and - at taps 0 .. 2 only, later the patch loads are older - the 8 patch loads
-      if constexpr (T <= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      if constexpr (T == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next patch is written
-      __builtin_amdgcn_s_barrier();             // barrier g
-#ifndef PC_ABL_NODMA
-      dma_issue();                              // tap g + 4 into slot g % 4 (the consumers have finished reading tap g)
-#endif
-    };
+    if constexpr (LNP) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // barrier "-1": the fragments of taps 0 .. 3 are in LDS
     for (int tile = mt_begin; tile < mt_end; tile += tstride) {
       for (int cc = 0; cc < nch; ++cc) {
-        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
-        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
-        cur ^= 1;
+#pragma unroll
+        for (int T = 0; T < 9; ++T) {
+          // the fragments of tap g + 1 (issued behind barrier g - 3) must have landed; younger in this wave's queue: taps g + 2, g + 3
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          __builtin_amdgcn_s_barrier();         // barrier g
+#ifndef PC_ABL_NODMA
+          dma_issue();                          // tap g + 4 into slot g % 4 (the consumers have finished reading tap g)
+#endif
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last DMAs target this workgroup's LDS: they must not outlive it)
@@ -240,22 +270,29 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
   }
 
   // ===================================================================================================================
-  // CONSUMERS (waves 0-3): block wblk = wave >> 1, column half wn0 = (wave & 1) * 64
+  // CONSUMERS (waves 0-3): block wblk = wave >> 1, column half wn0 = (wave & 1) * 64.
+  // v_mfma_f32_16x16x32_f16 / _bf16: a whole 32-channel chunk per instruction (K = 32), 4 x 4 tiles of 16 pixels x 16 columns per wave,
+  // 48 MFMAs of 16 cycles per tap.  Same FLOPs per cycle as the 32x32x16 shape, but the power-limited chip holds a higher clock on
+  // it: +6 % measured on this kernel with both shapes issued on the same operands (profiles/r03_halo_pc_mfma_shape.log).
+  // A operand of tile i: lane l = (c4 = l >> 4, p = l & 15) holds pixel 16 i + p (block row 2 i + (p >> 3), column p & 7), channels
+  // 8 c4 .. 8 c4 + 7; B operand of tile j: column 16 j + p, the same channels; D: column p, pixels 16 i + 4 c4 + r in register r.
   // ===================================================================================================================
-  constexpr int TM = 2, TN = 2;
+  constexpr int TI = 4, TJ = 4;
   const int wblk = wave >> 1, wn0 = (wave & 1) * 64;
-  const int i = lane & 31, h = lane >> 5;
-  const int pyl = i >> 3, pxl = i & 7;
-  f32x16 acc[TM][TN];
-  acc_zero<TM, TN>(acc);
-  u32x4 a[2][TM][2][PC_P], rb[2][TN][2][PC_P];
-  int cur = 0, slot = 0;       // patch buffer / ring slot of the tap whose operands are read NEXT
+  const int l16 = lane & 15, c4 = lane >> 4;
+  const int pyl = l16 >> 3, pxl = l16 & 7;
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 a[2][TI][PC_P], rb[2][TJ][PC_P];
+  int cur = 0, slot = 0;       // patch buffer / ring slot of the tap whose operands were read LAST
 
   // operands of one tap -> register set `buf`: A from the resident patch (shifted slots), B from the ring slot.  The addresses are
-  // computed BEFORE the tap's barrier (addr_ops: ~16 VALU in the shadow of the k-step-0 MFMAs), the reads issued behind it.
+  // computed BEFORE the tap's barrier (addr_ops: VALU in the shadow of the first half's MFMAs), the reads issued behind it.
   struct OpAddr {
-    const unsigned char* row[TM];
-    int hs[TM];
+    const unsigned char* row[TI];
     const unsigned char* bw;
   };
   auto addr_ops = [&](int tp, int patch_buf, int ring_slot) __attribute__((always_inline)) {
@@ -266,61 +303,54 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     asm volatile("" : "+v"(pyv), "+v"(pxv));       // (keeps the per-tap addresses out of the loop-invariant hoisting, conv_halo.hip)
     const unsigned char* patch_w = lds + patch_buf * PC_PATCHB + wblk * PC_BLKB;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int ry = tm * 4 + pyv + dyy, rx = pxv + dxx;
-      o.row[tm] = patch_w + (ry * PC_PITCH + rx) * 64;
-      o.hs[tm] = pc_sw(ry, rx);
+    for (int i = 0; i < TI; ++i) {
+      const int ry = 2 * i + pyv + dyy, rx = pxv + dxx;
+      o.row[i] = patch_w + (ry * PC_PITCH + rx) * 64 + ((c4 ^ pc_sw(ry, rx)) << 4);
     }
     int lv = lane;
     asm volatile("" : "+v"(lv));
-    o.bw = ring + ring_slot * PC_SLOTB + (wn0 >> 5) * 4096 + lv * 16;
+    o.bw = ring + ring_slot * PC_SLOTB + (wn0 >> 4) * 2048 + lv * 16;
     return o;
   };
   auto read_ops = [&](auto buf_c, const OpAddr& o) __attribute__((always_inline)) {
     constexpr int buf = decltype(buf_c)::value;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int pp = 0; pp < PC_P; ++pp) a[buf][i][pp] = *reinterpret_cast<const u32x4*>(o.row[i] + pp * PC_PLANEB);
 #pragma unroll
-        for (int pp = 0; pp < PC_P; ++pp)
-          a[buf][tm][ks][pp] = *reinterpret_cast<const u32x4*>(o.row[tm] + pp * PC_PLANEB + (((2 * ks + h) ^ o.hs[tm]) << 4));
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int pp = 0; pp < PC_P; ++pp)
-          rb[buf][tn][ks][pp] = *reinterpret_cast<const u32x4*>(o.bw + tn * 4096 + ks * 2048 + pp * 1024);
+      for (int pp = 0; pp < PC_P; ++pp) rb[buf][j][pp] = *reinterpret_cast<const u32x4*>(o.bw + j * 2048 + pp * 1024);
   };
-  auto mma_kstep = [&](auto par_c, auto ks_c) __attribute__((always_inline)) {
-    constexpr int par = decltype(par_c)::value, ks = decltype(ks_c)::value;
+  // MFMAs of row tiles 2 * half and 2 * half + 1 (24 instructions): hi * lo + lo * hi + hi * hi per (i, j)
+  auto mma_half = [&](auto par_c, auto half_c) __attribute__((always_inline)) {
+    constexpr int par = decltype(par_c)::value, half = decltype(half_c)::value;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int i = 2 * half; i < 2 * half + 2; ++i)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        f32x16 d = acc[tm][tn];
-        d = mfma16<HALF>(a[par][tm][ks][1], rb[par][tn][ks][0], d);
-        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][1], d);
-        d = mfma16<HALF>(a[par][tm][ks][0], rb[par][tn][ks][0], d);
-        acc[tm][tn] = d;
+      for (int j = 0; j < TJ; ++j) {
+        f32x4 d = acc[i][j];
+        d = mfma16k32<HALF>(a[par][i][1], rb[par][j][0], d);
+        d = mfma16k32<HALF>(a[par][i][0], rb[par][j][1], d);
+        d = mfma16k32<HALF>(a[par][i][0], rb[par][j][0], d);
+        acc[i][j] = d;
       }
   };
-  // one tap: [addresses of the next tap's operands | MFMAs of k-step 0]  barrier g  [16 LDS reads | MFMAs of k-step 1].
+  // one tap: [addresses of the next tap's operands | MFMAs of the first two row tiles]  barrier g  [16 LDS reads | MFMAs of the others].
   // One MFMA wave per SIMD: nothing else feeds the matrix pipe while this wave issues other instructions, so the address arithmetic
-  // is spread over the MFMAs of k-step 0 and the reads over those of k-step 1 (which use the OTHER register set): per MFMA two reads
-  // or a few VALU instructions fit into the 24 cycles it leaves the issue port free.
+  // is spread over the first 24 MFMAs and the reads over the second 24 (which use the OTHER register set).
   auto tap = [&](auto par_c, auto t_c) __attribute__((always_inline)) {
     constexpr int par = decltype(par_c)::value, T = decltype(t_c)::value;
     SGG_PRIO_HI();
     const int nslot = (slot + 1) & (PC_D - 1), ncur = T == 8 ? cur ^ 1 : cur;
     const OpAddr o = addr_ops(T == 8 ? 0 : T + 1, ncur, nslot);
-    mma_kstep(par_c, std::integral_constant<int, 0>{});
+    mma_half(par_c, std::integral_constant<int, 0>{});
 #if PC_INTERLEAVE
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       // VALU (addresses)
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);       // VALU (addresses)
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -329,17 +359,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     cur = ncur;
     read_ops(std::integral_constant<int, par ^ 1>{}, o);
 #if PC_INTERLEAVE
-    mma_kstep(par_c, std::integral_constant<int, 1>{});
+    mma_half(par_c, std::integral_constant<int, 1>{});
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // MFMA
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    for (int k = 0; k < 4; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #else
     __builtin_amdgcn_sched_barrier(0);
-    mma_kstep(par_c, std::integral_constant<int, 1>{});
+    mma_half(par_c, std::integral_constant<int, 1>{});
 #endif
     SGG_PRIO_LO();
     __builtin_amdgcn_sched_barrier(0);
@@ -351,25 +381,26 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
 #undef PC_TAP
   };
 
-  // ---- output addressing (as conv_halo3_kernel with 16-byte stores) ------------------------------------------------------------
+  // ---- output addressing: 16-byte stores.  After the quad transpose of a tile's four accumulator registers lane (c4, g = l16 >> 2,
+  // k = l16 & 3) holds pixel (block row 2 i + (c4 >> 1), column 4 (c4 & 1) + k), channels 16 j + 4 g .. + 3
   int o_grow, o_bx;
   {
     const int beta = mt_begin * PC_NB + wblk;
     o_grow = beta / p.bw;
     o_bx = beta % p.bw;
   }
-  const unsigned o_lane_b = (unsigned)(((4 * h + (lane & 3)) * p.out_ps) + ((lane & 31) >> 2) * 4) * 4u;
-  int o_goff[TN];
+  const int wn = p.out_rs;
+  const unsigned o_lane_b = (unsigned)((c4 >> 1) * wn + (4 * (c4 & 1) + (lane & 3)) * p.out_ps + (l16 >> 2) * 4) * 4u;
+  int o_goff[TJ];       // float offset of this wave's 16-column groups (two per 32-column group of the output's addressing)
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int gi = ((n0 + wn0) >> 5) + tn;
-    o_goff[tn] = (gi >> 1) * p.out_nA + (gi & 1) * p.out_nB;
+  for (int j = 0; j < TJ; ++j) {
+    const int gi = ((n0 + wn0) >> 5) + (j >> 1);
+    o_goff[j] = (gi >> 1) * p.out_nA + (gi & 1) * p.out_nB + (j & 1) * 16;
   }
   const float us_a = ldexpf(1.f, -ea), us_b = ldexpf(1.f, -eb);
-  float bias_v[TN];
+  float bias_v[TJ];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) bias_v[tn] = p.bias ? p.bias[n0 + wn0 + tn * 32 + acc_col(lane)] : 0.f;
-  const int wn = p.out_rs;
+  for (int j = 0; j < TJ; ++j) bias_v[j] = p.bias ? p.bias[n0 + wn0 + j * 16 + l16] : 0.f;
   constexpr int WN = 64;
 
   auto epilogue = [&](int tile) __attribute__((always_inline)) {
@@ -378,13 +409,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     const char* ob = reinterpret_cast<const char*>(p.out + (size_t)(o_grow * 8) * wn + (size_t)(o_bx * 8) * p.out_ps);
     float lsum = 0.f;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = HALF ? fmaf(acc[tm][tn][r] * us_a, us_b, bias_v[tn]) : acc[tm][tn][r] + bias_v[tn];
-          acc[tm][tn][r] = v;
+        for (int r = 0; r < 4; ++r) {
+          // (two exact power-of-two factors: |ea|, |eb| <= 100 keeps each one a normal float)
+          const float v = HALF ? fmaf(acc[i][j][r] * us_a, us_b, bias_v[j]) : acc[i][j][r] + bias_v[j];
+          acc[i][j][r] = v;
           lsum += v;
         }
 #ifdef PC_ABL_NOEPI
@@ -393,31 +425,30 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     if (live) {
 #endif
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v0 = acc[tm][tn][4 * q], v1 = acc[tm][tn][4 * q + 1], v2 = acc[tm][tn][4 * q + 2], v3 = acc[tm][tn][4 * q + 3];
-            sgg_quad_transpose4(v0, v1, v2, v3, lane);
-            const size_t so = ((size_t)(tm * 4 + q) * wn + o_goff[tn]) * sizeof(float);
-            sgg_out_store4(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), f32x4{v0, v1, v2, v3});
-          }
+        for (int j = 0; j < TJ; ++j) {
+          float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+          sgg_quad_transpose4(v0, v1, v2, v3, lane);
+          const size_t so = ((size_t)(2 * i) * wn + o_goff[j]) * sizeof(float);   // scalar: block rows 2 i, 2 i + 1
+          sgg_out_store4(reinterpret_cast<float*>(const_cast<char*>(ob) + so + o_lane_b), f32x4{v0, v1, v2, v3});
+        }
     }
 #ifdef PC_ABL_NOEPI
     if (p.B < 0) {
 #else
     if (p.tile_stats) {
 #endif
+      // (count, mean, M2, max dev) of this wave's 64 pixels x 64 channels (one 8x8 block: inside one sample)
       const float mean_w = wave_sum(lsum) * (1.f / (float)(64 * WN));
       float q = 0.f, dm = 0.f;
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[tm][tn][r] - mean_w;
+          for (int r = 0; r < 4; ++r) {
+            const float d = acc[i][j][r] - mean_w;
             q += d * d;
             dm = fmaxf(dm, fabsf(d));
           }
@@ -431,13 +462,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         o[3] = dm;
       }
     }
-    acc_zero<TM, TN>(acc);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     o_bx += adv_cols;
     o_grow += adv_rows;
     if (o_bx >= p.bw) { o_bx -= p.bw; ++o_grow; }
   };
 
-  if constexpr (LNP) __builtin_amdgcn_s_barrier();      // (matches the producers' barrier behind their lnp_s fill)
+  if constexpr (LNP) __builtin_amdgcn_s_barrier();      // (matches the producers' barrier behind the lnp_s fill)
   __builtin_amdgcn_s_barrier();                          // barrier "-1"
   read_ops(std::integral_constant<int, 0>{}, addr_ops(0, 0, 0));         // tap 0: patch buffer 0, ring slot 0
   // (C % 64 == 0: an even number of chunks; the register-set parity flips once per chunk of nine taps)
@@ -456,8 +490,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
 #ifndef SGG_HALO_PC
 #define SGG_HALO_PC 1
 #endif
-int sgg_halo_pc_applicable(const HaloParams& p, int precision) {
-  return SGG_HALO_PC && (precision == 2 || precision == 3) && p.N % 128 == 0 && p.C % 64 == 0 && p.C <= 512;
+int sgg_halo_pc_applicable(int C, int N, int precision) {
+  return SGG_HALO_PC && (precision == 2 || precision == 3) && N % 128 == 0 && C % 64 == 0 && C <= 512;
 }
 
 void sgg_halo_pc_launch(const HaloParams& p_, int precision, hipStream_t st) {

@@ -73,6 +73,16 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 
 }
 
 
+// the K = 32 shape (16 x 16 output tile, 4 accumulator registers, 16 cycles): same FLOPs per cycle; the chip holds a higher clock on it
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+template <bool HALF>
+__device__ __forceinline__ f32x4_acc mfma16k32(const u32x4& a, const u32x4& b, f32x4_acc c) {
+  if constexpr (HALF)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // LN prologue of the patch staging: 8 channels of y -> ELU(y * inv_c + shift_c), inv_c = gamma_c * rstd, shift_c = beta_c - mean * inv_c
 // (the arithmetic of ln_apply_elu_kernel; ELU's negative branch through v_exp_f32: |error| <= 1.2e-7 absolute).
 // `zero`: the pixel lies outside the image - the padding is a zero ACTIVATION.

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void wp_transpose_kernel(WpArgs a) {
 }
 
 // phase B: the pre-split copies.  Per layer the forward operand's items come first, then the dgrad operand's.
-//   layout 0: planes [P][n] (split_weights_kernel); layouts 1..3: MFMA B fragments [tap][C/32][N/32][k-step][plane][lane] x 16 B
+//   layout 0: planes [P][n] (split_weights_kernel); layouts 1..3: MFMA B fragments [tap][C/32][N/32][k-step][plane][lane] x 16 B;
+//   layout 4: the fragments of the K = 32 MFMA shape [tap][C/32][N/16][plane][lane] x 16 B (same size, same number of items)
 template <int P, bool HALF>
 __global__ __launch_bounds__(256) void wp_split_kernel(WpArgs a) {
   const int l = wp_layer_of(a, blockIdx.x);
@@ -111,6 +112,23 @@ __global__ __launch_bounds__(256) void wp_split_kernel(WpArgs a) {
       split8<P, HALF>(reinterpret_cast<const f32x4*>(src)[2 * idx], reinterpret_cast<const f32x4*>(src)[2 * idx + 1], scale, pl);
 #pragma unroll
       for (int pp = 0; pp < P; ++pp) reinterpret_cast<u32x4*>(out)[(long long)pp * items + idx] = pl[pp];
+    } else if (lay == 4) {
+      // fragments of v_mfma_f32_16x16x32 (conv_halo_pc.hip): [tap][C/32][N/16][plane][lane] x 16 B, lane l = column 16 t + (l & 15),
+      // channels 32 c + 8 (l >> 4) .. + 7 (sgg_conv_split_weights_frag16)
+      if constexpr (P == 2) {
+        const int nch = C >> 5, ntl = N >> 4;
+        const int lane = (int)(idx & 63);
+        long long r = idx >> 6;
+        const int ntile = (int)(r % ntl); r /= ntl;
+        const int cc = (int)(r % nch);
+        const int tap = (int)(r / nch);
+        const int n = ntile * 16 + (lane & 15), k = cc * 32 + 8 * (lane >> 4);
+        const float* s = src + ((size_t)tap * N + n) * C + k;
+        split8<2, HALF>(*reinterpret_cast<const f32x4*>(s), *reinterpret_cast<const f32x4*>(s + 4), scale, pl);
+        const size_t o = (((size_t)(tap * nch + cc) * ntl + ntile) * 2) * 64 + lane;
+        reinterpret_cast<u32x4*>(out)[o] = pl[0];
+        reinterpret_cast<u32x4*>(out)[o + 64] = pl[1];
+      }
     } else if constexpr (P == 2) {
       const int nch = C >> 5, ntl = N >> 5;
       const int lane = (int)(idx & 63), ks = (int)((idx >> 6) & 1);
@@ -154,7 +172,7 @@ extern "C" int sgg_conv_prepare_weights(const sgg_conv_weight_desc* layers, int 
     SGG_CHECK_ARG(!s2d || (d.w3 && d.w3_hwoi && d.taps == 25), "sgg_conv_prepare_weights: layer %d: layout 3 needs w3 / w3_hwoi and 25 taps", i);
     SGG_CHECK_ARG(!(d.ws_fwd || d.ws_bwd) || ((long long)d.taps * d.cin * d.cout) % 8 == 0, "sgg_conv_prepare_weights: layer %d: size", i);
     SGG_CHECK_ARG(!(d.ws_fwd || d.ws_bwd) || pg != 2 || d.amax, "sgg_conv_prepare_weights: layer %d: precision 1 / 2 need the amax word", i);
-    SGG_CHECK_ARG(d.layout_fwd >= 0 && d.layout_fwd <= 3 && d.layout_bwd >= 0 && d.layout_bwd <= 3 &&
+    SGG_CHECK_ARG(d.layout_fwd >= 0 && d.layout_fwd <= 4 && d.layout_bwd >= 0 && d.layout_bwd <= 4 &&
                       ((d.layout_fwd == 0 && d.layout_bwd == 0) || (d.cin % 32 == 0 && d.cout % 32 == 0)),
                   "sgg_conv_prepare_weights: layer %d: fragment layouts need channels %% 32 == 0", i);
     SGG_CHECK_ARG(pg != 6 || (d.layout_fwd == 0 && d.layout_bwd == 0), "sgg_conv_prepare_weights: precision 6 has the plane layout only");

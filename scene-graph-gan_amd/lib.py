@@ -34,6 +34,7 @@ SIGNATURES = {
     "sgg_conv_s2d_weights": (_i, [_vp, _vp, _i, _i, _vp]),
     "sgg_conv_prepare_weights": (_i, [_vp, _i, _i, _vp]),
     "sgg_conv_split_weights_frag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sgg_conv_split_weights_frag16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
     "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp]),
@@ -254,9 +255,10 @@ class HipKernels:
         return w
 
     def conv_wsplit_layout(self, k, stride, H, W, cin, cout):
-        """Layout the conv entry points want for the pre-split weights of this layer: 0 = planes, 1 / 2 = MFMA fragment order
-        (1: halo-resident 3x3 stride-1 kernel, 2: band-resident 5x5 stride-2 kernel; H, W = the full-resolution grid;
-        SGG_CONV_HALO=0 keeps every layer on the gather kernel)."""
+        """Layout the conv entry points want for the pre-split weights of this layer: 0 = planes, 1 / 2 / 3 = MFMA fragment order
+        (1: halo-resident 3x3 stride-1 kernel, 2: band-resident 5x5 stride-2 kernel, 3: conv1_3 through the space-to-depth view;
+        H, W = the full-resolution grid), 4 = the fragments of the K = 32 MFMA shape for the producer / consumer 3x3 kernel
+        (128-column tiles); SGG_CONV_HALO=0 keeps every layer on the gather kernel."""
         if not self.conv_halo:
             return 0
         return self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
@@ -265,6 +267,11 @@ class HipKernels:
         """w fp32 [kh, kw, N, C] -> out int16 [P, n] sixteen-bit planes (layout 0) or MFMA B fragments (layout 1)."""
         self._dev(w, out, amax)
         amax = self._amax_or_compute(w, amax, 2)
+        if layout == 4:         # fragments of the K = 32 MFMA shape (producer / consumer 3x3 kernel)
+            kh, kw, n, c = w.shape
+            self._check(self.lib.sgg_conv_split_weights_frag16(_p(w), _p(out), kh * kw, n, c, self.conv_precision, _p(amax),
+                                                               self._stream()), "sgg_conv_split_weights_frag16")
+            return
         if layout in (1, 2, 3):
             kh, kw, n, c = w.shape
             self._check(self.lib.sgg_conv_split_weights_frag(_p(w), _p(out), kh * kw, n, c, self.conv_precision, _p(amax),
@@ -306,6 +313,10 @@ class HipKernels:
         return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], k, k, stride, self.conv_precision,
                                                        layout)
 
+    def halo_pc_symbol(self, lnp=False):
+        """Kernel symbol of the producer / consumer 3x3 kernel (csrc/conv_halo_pc.hip; w_split_layout 4)."""
+        return "conv_halo3_pc_kernel<%s,%s>" % ("true" if self.conv_precision == 2 else "false", "true" if lnp else "false")
+
     def halo_symbol(self, n_out, n_in, lnp=False):
         """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_halo.hip: sgg_halo_launch picks (default build)."""
         tile = "2,128,2,2" if n_out % 128 == 0 else ("2,64,2,2" if n_out % 64 == 0 else "2,32,2,1")
@@ -330,7 +341,8 @@ class HipKernels:
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
+        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_pc_symbol(ln is not None) if w_split_layout == 4 else
+                                                             self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
                                                              self.halo_symbol(d[6], 4 * d[3], ln is not None) if w_split_layout == 3 else
                                                              self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None, ln is not None) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
@@ -346,7 +358,7 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        sym = self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
+        sym = self.halo_pc_symbol() if w_split_layout == 4 else self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
                                                                           self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False) if w_split_layout == 2 else
                                                                           self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
@@ -410,13 +422,13 @@ class HipKernels:
             return False
         lay = self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
         # (layout 2: the band-resident forward has the prologue; its wgrad only on grids the 8x8-block halo kernel tiles)
-        return lay in (1, 3) or (lay == 2 and (H // 2) % 8 == 0 and (W // 2) % 8 == 0)
+        return lay in (1, 3, 4) or (lay == 2 and (H // 2) % 8 == 0 and (W // 2) % 8 == 0)
 
     def ln_prologue_fwd_ok(self, k, stride, H, W, cin, cout):
         """True if conv_fwd of this layer can apply the producing layer's LayerNorm + ELU itself (forward-only passes): the
         resident kernels (halo incl. conv1_3 through the space-to-depth view, band-resident 5x5 stride 2)."""
         return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
-                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 2, 3))
+                self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 2, 3, 4))
 
     def ln_workspace_bytes(self, shape):
         B, H, W, C = shape

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 O=$R/gpurun_out/${1:-pc2}
 mkdir -p $O
-timeout -k 5 300 python -m pytest tests/test_kernels_gpu.py -k "halo or prologue or epilogue" -m gpu -q -x > $O/t1.log 2>&1 || { tail -40 $O/t1.log; exit 1; }
+timeout -k 5 300 python -m pytest tests/test_kernels_gpu.py -k "halo or prologue or epilogue or prepare_weights" -m gpu -q -x > $O/t1.log 2>&1 || { tail -40 $O/t1.log; exit 1; }
 tail -2 $O/t1.log
 timeout -k 10 400 python -m pytest tests/test_fullsize_conv_gpu.py tests/test_step_gpu.py -m gpu -q -x > $O/t3.log 2>&1 || { tail -40 $O/t3.log; exit 1; }
 tail -2 $O/t3.log

@@ -60,7 +60,7 @@ def test_step_is_unchanged_beside_mfma_kernels_of_another_stream(hip):
         for _ in range(times):
             hip.conv_dgrad(dy, lay["w"], dx, lay["s"], lay["ws_bwd"], None, T._am(2, j), lay["ws_layout_bwd"])
 
-    assert T.layers[7]["ws_layout"] == 2 and T.layers[6]["ws_layout"] == 1
+    assert T.layers[7]["ws_layout"] == 2 and T.layers[6]["ws_layout"] in (1, 4)     # (4: the producer / consumer 3x3 kernel)
 
     def run(beside):
         gs = _new_step(hip)

@@ -424,8 +424,11 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
     hip.conv_precision = mode
     try:
         tol = {2: 2e-5, 3: 1e-4, **ONE_PIECE_TOL}[mode]
-        assert hip.conv_wsplit_layout(3, 1, H, W, Ci, Co) == 1
-        assert hip.conv_wsplit_layout(3, 1, H + 1, W, Ci, Co) == 0 and hip.conv_wsplit_layout(5, 2, H, W, Ci, Co) != 1
+        lay_f, lay_b = hip.conv_wsplit_layout(3, 1, H, W, Ci, Co), hip.conv_wsplit_layout(3, 1, H, W, Co, Ci)
+        pc_f = mode in (2, 3) and Co % 128 == 0 and Ci % 64 == 0      # producer / consumer kernel (conv_halo_pc.hip): w_split_layout 4
+        pc_b = mode in (2, 3) and Ci % 128 == 0 and Co % 64 == 0
+        assert lay_f == (4 if pc_f else 1) and lay_b == (4 if pc_b else 1), (lay_f, lay_b)
+        assert hip.conv_wsplit_layout(3, 1, H + 1, W, Ci, Co) == 0 and hip.conv_wsplit_layout(5, 2, H, W, Ci, Co) not in (1, 4)
         x, w, b = rnd((B, H, W, Ci), 11), rnd((3, 3, Ci, Co), 12, 1.0 / math.sqrt(9 * Ci)), rnd((Co,), 13, 0.1)
         dy = rnd((B, H, W, Co), 14)
         y_ref = torch.empty((B, H, W, Co), dtype=torch.float64)
@@ -455,6 +458,33 @@ def test_conv_halo_fwd_dgrad(hip, ref, case, mode):
         y_g = torch.empty_like(y)
         hip.conv_fwd(xd, wd, wf, bd, y_g, 1)
         close(y, y_g.cpu(), rtol=5e-6 if mode in (2, 3) else 2.0 * tol, what="halo vs gather")
+        # the producer / consumer kernel (layout 4: fragments of the K = 32 MFMA shape) where the library picks it: same pieces and
+        # products again, against fp64 and against the 4-wave kernel
+        if lay_f == 4:
+            ws4 = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+            hip.split_weights(wf, ws4, layout=4)
+            y4 = torch.full((B, H, W, Co), float("nan"), device="cuda")
+            hip.conv_fwd(xd, wd, wf, bd, y4, 1, ws4, w_split_layout=4)
+            close(y4, y_ref, rtol=tol, what="producer/consumer conv_fwd %s" % (case,))
+            close(y4, y.cpu(), rtol=5e-6, what="producer/consumer vs 4-wave kernel")
+            nts4 = hip.conv_tile_stats_count((B, H, W, Co), Ci, 3, 1, 4)
+            ts4 = torch.full((B, nts4, 4), float("nan"), device="cuda")
+            y5 = torch.empty_like(y4)
+            hip.conv_fwd(xd, wd, wf, bd, y5, 1, ws4, tile_stats=ts4, w_split_layout=4)
+            assert torch.equal(y5, y4)
+            g4, b4 = dev(1.0 + rnd((Co,), 15, 0.2)), dev(rnd((Co,), 16, 0.2))
+            a_t, a_p = torch.empty_like(y4), torch.empty_like(y4)
+            st_t, st_p = torch.empty((B, 2), device="cuda"), torch.empty((B, 2), device="cuda")
+            hip.ln_elu_fwd(y4, g4, b4, a_t, st_t, tile_stats=ts4)
+            hip.ln_elu_fwd(y4, g4, b4, a_p, st_p)
+            close(st_t, st_p.cpu(), rtol=1e-6, what="producer/consumer tile statistics vs statistics pass")
+        if lay_b == 4:
+            ws4b = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+            hip.split_weights(wd, ws4b, layout=4)
+            dx4 = torch.full((B, H, W, Ci), float("nan"), device="cuda")
+            hip.conv_dgrad(dyd, wd, dx4, 1, ws4b, w_split_layout=4)
+            close(dx4, dx_ref, rtol=tol, what="producer/consumer conv_dgrad %s" % (case,))
+            close(dx4, dx.cpu(), rtol=5e-6, what="producer/consumer dgrad vs 4-wave kernel")
         # LayerNorm partial statistics from the halo epilogue
         nts = hip.conv_tile_stats_count((B, H, W, Co), Ci, 3, 1, 1)
         assert nts in ((H * W // 64) * (Co // (64 if Co % 64 == 0 else 32)),
@@ -794,6 +824,13 @@ def test_layernorm_prologue_fwd_wgrad(hip, ref, case, mode):
         y_u = torch.empty_like(y)
         hip.conv_fwd(a, wd, wf, bd, y_u, 1, ws_f, w_split_layout=1)
         close(y, y_u.cpu(), rtol=5e-6, what="fused vs unfused forward")
+        if hip.conv_wsplit_layout(3, 1, H, W, Ci, Co) == 4:      # the producer / consumer kernel applies the prologue in its patch waves
+            ws4 = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+            hip.split_weights(wf, ws4, am[1:2], layout=4)
+            y4 = torch.full((B, H, W, Co), float("nan"), device="cuda")
+            hip.conv_fwd(y0d, wd, wf, bd, y4, 1, ws4, am[0:1], am[1:2], None, 4, ln=ln)
+            close(y4, y_ref, rtol=tol, what="producer/consumer forward with LN prologue %s" % (case,))
+            close(y4, y.cpu(), rtol=5e-6, what="producer/consumer vs 4-wave kernel, LN prologue")
         dw_u = torch.empty_like(dw)
         hip.conv_wgrad(a, dyd, dw_u, 1)
         close(dw, dw_u.cpu(), rtol=5e-6, what="fused vs unfused wgrad")
