@@ -9,12 +9,10 @@
 // same bytes in every wave of a column half) and 8.5 % on the patch staging.  Here ONE 8-wave workgroup owns the CU:
 //   * waves 0-3, the CONSUMERS (2 blocks x 2 column halves as before, 64 pixels x 64 columns each), issue nothing but LDS reads,
 //     MFMAs and - never waited for - the output stores: no vector-memory load, hence no vmcnt wait, anywhere in their loop;
-//   * waves 4-5, the WEIGHT PRODUCERS, move the weight fragments of the next taps L2 -> LDS by LDS-DMA (buffer_load ... lds, no VGPRs,
-//     no VALU) into a ring of four 16-KiB tap slots shared by the four consumers: the L1 traffic of the weight operand halves, the
-//     consumers read it at LDS bandwidth;
-//   * waves 6-7, the PATCH PRODUCERS, stage the activation patch two 32-channel chunks ahead (load, f32 -> 2 x fp16 split or the
-//     LayerNorm + ELU prologue, LDS write).  Separate waves because vmcnt retires in order: in one queue every wait for a weight
-//     DMA would wait for the (HBM-latency) patch loads issued before it.
+//   * waves 4-7, the PRODUCERS, own the vector-memory queue: the weight fragments of the next taps go L2 -> LDS by LDS-DMA
+//     (buffer_load ... lds, no VGPRs, no VALU) into a ring of four 16-KiB tap slots shared by the four consumers (the L1 traffic of
+//     the weight operand halves, the consumers read it at LDS bandwidth), and the activation patch is staged two 32-channel chunks
+//     ahead (load, f32 -> 2 x fp16 split or the LayerNorm + ELU prologue, LDS write).
 // One raw s_barrier per tap (24 MFMAs per consumer) is the only synchronisation: behind barrier g the producers guarantee that the
 // fragments of tap g+1 (and, at a chunk's last tap, the next patch) have landed, the consumers that they no longer read slot g.
 // Both roles run the SAME loop nest (tile, chunk, nine statically unrolled taps) with exactly one barrier per tap.
@@ -35,7 +33,7 @@
 #ifndef PC_INTERLEAVE
 #define PC_INTERLEAVE 1
 #endif
-#define PC_NPASS 7                        // 800 (block, patch pixel, 8-channel group) items over the 128 patch-producer threads
+#define PC_NPASS 4                        // 800 (block, patch pixel, 8-channel group) items over the 256 producer threads
 
 // XOR swizzle of the 16-byte chunk index inside a pixel's 64-byte row (write and read side).  With the 16x16x32 operand read (16
 // lanes = two patch rows x 8 pixels take one chunk each, four such groups per ds_read_b128) every read of every tap is conflict free
@@ -47,9 +45,11 @@ typedef __attribute__((address_space(3))) void* pc_lds_ptr;
 
 template <bool HALF, bool LNP>
 __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PC_PATCHB + PC_D * PC_SLOTB];
-  __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 1024 : 4];      // gamma[0..511], beta at +512 (C <= 512: host check)
+  // ONE __shared__ object: with the LayerNorm parameters in an array of their own the compiler waits vmcnt(0) - for every weight DMA
+  // in flight - in front of each patch write (cdna_hip_programming.md, "a second __shared__ object beside the glds staging array")
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PC_PATCHB + PC_D * PC_SLOTB + (LNP ? 4096 : 0)];
   unsigned char* const ring = lds + 2 * PC_PATCHB;
+  float* const lnp_s = reinterpret_cast<float*>(lds + 2 * PC_PATCHB + PC_D * PC_SLOTB);      // gamma[0..511], beta at +512 (C <= 512: host check)
 
   // ---- persistent workgroup: as conv_halo3_kernel (XCD k owns a contiguous eighth of the M-tiles, its workgroups walk it interleaved)
   const int ntiles_n = p.N / 128;
@@ -71,17 +71,21 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     eb = scale_exp_from_amax(*p.amax_w);
   }
 
-  if (wave >= 6) {
+  if (wave >= 4) {
     // =================================================================================================================
-    // PATCH PRODUCERS (waves 6-7, pt = 0 .. 127): the patch of chunk c + 2 is LOADED at tap 0 of chunk c (two register sets), the
-    // patch of chunk c + 1 is split and WRITTEN at taps 1 .. 7 of chunk c: a load has nine taps to arrive.  (Waves of their own:
-    // vmcnt retires in order, so in one queue with the weight DMAs every wait for a DMA would also wait for the patch loads.)
+    // PRODUCERS (waves 4-7, pt = 0 .. 255).  Patch: the patch of chunk c + 2 is LOADED at tap 0 of chunk c (two register sets), the
+    // patch of chunk c + 1 is split and WRITTEN at taps 1 .. 4 of chunk c: a load has at least ten taps to arrive before its first
+    // use, and three before the first weight-DMA wait that covers it (vmcnt retires in order).  Weights: tap (d_cc, d_tap) of the
+    // fragment stream -> ring slot by LDS-DMA, four of the tap's sixteen 1-KiB pieces per wave.
+    // (Two weight waves + two patch waves were measured too: equal without the LayerNorm prologue, 4 % slower with it - two waves
+    //  then carry all of its v_exp work.)
     // =================================================================================================================
-    const int pt = tid - 384;
+    const int pt = tid - 256, pw = wave - 4;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
     const float sa = ldexpf(1.f, ea);
     if constexpr (LNP) {
-      for (int c = pt; c < p.ln_nc; c += 128) {
+      for (int c = pt; c < p.ln_nc; c += 256) {
         lnp_s[c] = p.ln_gamma[c];
         lnp_s[512 + c] = p.ln_beta[c];
       }
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     int it_meta[PC_NPASS];      // bits 0..19 LDS byte offset inside a plane, 20..23 border bits, 24 block, 26..27 channel group, 28 valid
 #pragma unroll
     for (int j = 0; j < PC_NPASS; ++j) {
-      const int it = pt + 128 * j;
+      const int it = pt + 256 * j;
       const int blk = (it / 400) & 1, r = it % 400;
       const int px = r >> 2, ch8 = r & 3;
       const int ry = px / 10, rx = px % 10;
@@ -163,40 +167,66 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         }
       }
     };
-    // split (or LayerNorm + ELU, then split) pass j of register set S and write it into patch buffer `dst`
+    // LN prologue of half `hf` (4 channels) of pass j of register set S, in place
+    auto stage_ln_half = [&](auto s_c, auto j_c, auto hf_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(s_c)::value, j = decltype(j_c)::value, hf = decltype(hf_c)::value;
+      const int blk = (it_meta[j] >> 24) & 1;
+      const float mu = blk ? ld_mu[S][1] : ld_mu[S][0], rs = blk ? ld_rs[S][1] : ld_rs[S][0];
+      const int cb = ((ld_cc[S] * 32) & (p.ln_nc - 1)) + ((it_meta[j] >> 26) & 3) * 8 + 4 * hf;
+      ln_elu4(pre[S][j][hf], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad[S] >> j) & 1);
+    };
+    // split pass j of register set S (LNP: after both stage_ln_half) and write it into patch buffer `dst`
     auto stage_write_pass = [&](auto s_c, auto j_c, unsigned char* dst) __attribute__((always_inline)) {
       constexpr int S = decltype(s_c)::value, j = decltype(j_c)::value;
-      if constexpr (LNP) {
-        const int blk = (it_meta[j] >> 24) & 1;
-        const float mu = blk ? ld_mu[S][1] : ld_mu[S][0], rs = blk ? ld_rs[S][1] : ld_rs[S][0];
-        const int cb = ((ld_cc[S] * 32) & (p.ln_nc - 1)) + ((it_meta[j] >> 26) & 3) * 8;
-        ln_elu8(pre[S][j][0], pre[S][j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad[S] >> j) & 1);
-      }
       u32x4 pl[PC_P];
       split8<PC_P, HALF>(pre[S][j][0], pre[S][j][1], sa, pl);
-      // (passes 0 .. 5 cover items 0 .. 767: always valid; the last pass holds 32 items)
+      // (passes 0 .. 2 cover items 0 .. 767: always valid; the last pass holds 32 items)
       if (j < PC_NPASS - 1 || ((it_meta[j] >> 28) & 1)) {
 #pragma unroll
         for (int pp = 0; pp < PC_P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PC_PLANEB + (it_meta[j] & 0xfffff)) = pl[pp];
       }
     };
-    auto write_all = [&](auto s_c, unsigned char* dst) __attribute__((always_inline)) {
-      stage_write_pass(s_c, std::integral_constant<int, 0>{}, dst); stage_write_pass(s_c, std::integral_constant<int, 1>{}, dst);
-      stage_write_pass(s_c, std::integral_constant<int, 2>{}, dst); stage_write_pass(s_c, std::integral_constant<int, 3>{}, dst);
-      stage_write_pass(s_c, std::integral_constant<int, 4>{}, dst); stage_write_pass(s_c, std::integral_constant<int, 5>{}, dst);
-      stage_write_pass(s_c, std::integral_constant<int, 6>{}, dst);
+    // ---- weight fragments: this wave moves pieces 4 pw .. 4 pw + 3 of the tap's sixteen 1-KiB pieces [n-tile 16][plane]
+    const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
+    const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * 4096u + (unsigned)lane * 16u;
+    int d_cc = 0, d_tap = 0, d_slot = 0;
+    auto dma_issue = [&]() __attribute__((always_inline)) {
+      const unsigned base = (unsigned)(d_tap * nch + d_cc) * w_slab + w_lane;
+      unsigned char* dst = ring + d_slot * PC_SLOTB + pw * 4096;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (pc_lds_ptr)(dst + q * 1024), 16, base + (unsigned)(q * 1024), 0, 0, 0);
+      if (++d_tap == 9) {
+        d_tap = 0;
+        if (++d_cc == nch) d_cc = 0;
+      }
+      d_slot = (d_slot + 1) & (PC_D - 1);
     };
+
+    // ---- prologue: the first PC_D taps of weights, the patches of chunks 0 (written) and 1 (in flight) ---------------------------
+#pragma unroll
+    for (int k = 0; k < PC_D; ++k) dma_issue();
     int cur = 0;                                // patch buffer the consumers read in the current chunk
     if constexpr (LNP) {
-      // lnp_s is filled and read by the 128 patch-producer threads: one extra barrier (matched by every other wave)
+      // lnp_s is filled and read by the 256 producer threads: one extra barrier (matched by the consumers)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     stage_load(std::integral_constant<int, 0>{});            // chunk 0
-    write_all(std::integral_constant<int, 0>{}, lds);
+    auto full_pass = [&](auto s_c, auto j_c, unsigned char* dst) __attribute__((always_inline)) {
+      if constexpr (LNP) {
+        stage_ln_half(s_c, j_c, std::integral_constant<int, 0>{});
+        stage_ln_half(s_c, j_c, std::integral_constant<int, 1>{});
+      }
+      stage_write_pass(s_c, j_c, dst);
+    };
+    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds);
+    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, lds);
+    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, lds);
+    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, lds);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     stage_load(std::integral_constant<int, 1>{});            // chunk 1: in flight across the prologue barrier
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 is in LDS
+    __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 and the fragments of taps 0 .. 3 are in LDS
 
     // one tap of chunk c (register-set parity S = c & 1): T = 0 .. 8
     auto tap = [&](auto s_c, auto t_c) __attribute__((always_inline)) {
@@ -205,11 +235,31 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       //  after the prologue's, -DPC_ABL_NOEPI no output stores / statistics)
 #ifndef PC_ABL_NOSTAGE
       if constexpr (T == 0) stage_load(s_c);                                    // chunk c + 2 -> set S (chunk c's data left it a chunk ago)
-      if constexpr (T >= 1 && T <= 7)                                           // chunk c + 1 (set S ^ 1) -> the buffer the consumers do not read
+      // chunk c + 1 (set S ^ 1) -> the buffer the consumers do not read.  Without the LN prologue one pass (25 VALU) per tap at taps
+      // 1 .. 4; with it half a pass per tap at taps 1 .. 8: the vector issue port of a SIMD is shared with the consumer wave, whose
+      // 16x16x32 MFMAs alone hold it half of the time, and a whole pass of the prologue (16 v_exp) in one tap makes the barrier late
+      if constexpr (LNP) {
+        if constexpr (T >= 1) {
+          constexpr int J = (T - 1) >> 1, HF = (T - 1) & 1;
+          stage_ln_half(std::integral_constant<int, S ^ 1>{}, std::integral_constant<int, J>{}, std::integral_constant<int, HF>{});
+          if constexpr (HF == 1) stage_write_pass(std::integral_constant<int, S ^ 1>{}, std::integral_constant<int, J>{}, lds + (cur ^ 1) * PC_PATCHB);
+        }
+      } else if constexpr (T >= 1 && T <= 4) {
         stage_write_pass(std::integral_constant<int, S ^ 1>{}, std::integral_constant<int, T - 1>{}, lds + (cur ^ 1) * PC_PATCHB);
+      }
 #endif
+      // fragments of tap g + 1 (issued behind barrier g - 3) must have landed.  Younger than them in this wave's vmcnt queue: the
+      // DMAs of taps g + 2, g + 3 (8 instructions) and - at taps 0 .. 2 only, later the patch loads of tap 0 are older - 8 patch loads
+      // (the BUILTIN, not inline asm: the compiler's own wait insertion must see these waits - with asm it believes every DMA since
+      //  the kernel's start is still in flight, its count outgrows the 6-bit counter and it falls back to vmcnt(0) at the chunk loop's
+      //  head and in front of the patch writes: a full L2 round trip in the producers once per chunk, the barrier late by as much)
+      if constexpr (T <= 2) __builtin_amdgcn_s_waitcnt(0x4F70);      // vmcnt(16)
+      else __builtin_amdgcn_s_waitcnt(0x0F78);                        // vmcnt(8)
       if constexpr (T == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next patch is written
       __builtin_amdgcn_s_barrier();             // barrier g
+#ifndef PC_ABL_NODMA
+      dma_issue();                              // tap g + 4 into slot g % 4 (the consumers have finished reading tap g)
+#endif
     };
     auto chunk = [&](auto s_c) __attribute__((always_inline)) {
       tap(s_c, std::integral_constant<int, 0>{}); tap(s_c, std::integral_constant<int, 1>{}); tap(s_c, std::integral_constant<int, 2>{});
@@ -221,48 +271,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       for (int cc = 0; cc < nch; cc += 2) {
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
-      }
-    }
-    return;
-  }
-  if (wave >= 4) {
-    // =================================================================================================================
-    // WEIGHT PRODUCERS (waves 4-5): tap (d_cc, d_tap) of the fragment stream -> ring slot by LDS-DMA; this wave moves pieces
-    // 8 dw .. 8 dw + 7 of the tap's sixteen 1-KiB pieces [n-tile][k-step][plane]
-    // =================================================================================================================
-    const int dw = wave - 4;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
-    const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
-    const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)dw * 8192u + (unsigned)lane * 16u;
-    int d_cc = 0, d_tap = 0, d_slot = 0;
-    auto dma_issue = [&]() __attribute__((always_inline)) {
-      const unsigned base = (unsigned)(d_tap * nch + d_cc) * w_slab + w_lane;
-      unsigned char* dst = ring + d_slot * PC_SLOTB + dw * 8192;
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (pc_lds_ptr)(dst + q * 1024), 16, base + (unsigned)(q * 1024), 0, 0, 0);
-      if (++d_tap == 9) {
-        d_tap = 0;
-        if (++d_cc == nch) d_cc = 0;
-      }
-      d_slot = (d_slot + 1) & (PC_D - 1);
-    };
-#pragma unroll
-    for (int k = 0; k < PC_D; ++k) dma_issue();
-    if constexpr (LNP) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();               // barrier "-1": the fragments of taps 0 .. 3 are in LDS
-    for (int tile = mt_begin; tile < mt_end; tile += tstride) {
-      for (int cc = 0; cc < nch; ++cc) {
-#pragma unroll
-        for (int T = 0; T < 9; ++T) {
-          // the fragments of tap g + 1 (issued behind barrier g - 3) must have landed; younger in this wave's queue: taps g + 2, g + 3
-          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          __builtin_amdgcn_s_barrier();         // barrier g
-#ifndef PC_ABL_NODMA
-          dma_issue();                          // tap g + 4 into slot g % 4 (the consumers have finished reading tap g)
-#endif
-        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last DMAs target this workgroup's LDS: they must not outlive it)

@@ -83,6 +83,20 @@ __device__ __forceinline__ f32x4_acc mfma16k32(const u32x4& a, const u32x4& b, f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// half of ln_elu8: 4 channels (the producer waves of conv_halo_pc.hip spread the prologue of an 8-channel item over two taps)
+__device__ __forceinline__ void ln_elu4(f32x4& v0, const float* __restrict__ gam, const float* __restrict__ bet, float mean, float rstd,
+                                        bool zero) {
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam), b0 = *reinterpret_cast<const f32x4*>(bet);
+  const f32x4 i0 = g0 * rstd;
+  const f32x4 s0 = b0 - i0 * mean;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float z0 = fmaf(v0[q], i0[q], s0[q]);
+    const float e0 = __expf(z0) - 1.f;
+    v0[q] = zero ? 0.f : (z0 > 0.f ? z0 : e0);
+  }
+}
+
 // LN prologue of the patch staging: 8 channels of y -> ELU(y * inv_c + shift_c), inv_c = gamma_c * rstd, shift_c = beta_c - mean * inv_c
 // (the arithmetic of ln_apply_elu_kernel; ELU's negative branch through v_exp_f32: |error| <= 1.2e-7 absolute).
 // `zero`: the pixel lies outside the image - the padding is a zero ACTIVATION.
