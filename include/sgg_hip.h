@@ -136,6 +136,12 @@ int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamm
                               const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
                               float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Builds with -DSGG_LN_BWD_FUSED=1 (not the default: measured equal, profiles/r03_ln_bwd_one_pass.log) run sgg_layernorm_hwc_elu_bwd
+ * as ONE kernel that reads y and da once where a sample splits into at most 128 pieces of 16384 elements: a workgroup holds its
+ * piece in registers while the two sums over the sample are exchanged between workgroups.  That wait is bounded; *timed_out = 1
+ * reports that the last call on `workspace` gave up on it (dy of that call is then not valid).  Always 0 in the default build.
+ * Synchronises with `stream`: an aid for tests, not part of the training step. */
+int sgg_layernorm_hwc_elu_bwd_status(const void* workspace, int B, int HW, int C, int* timed_out, void* stream);
 
 /* dgamma == dbeta == NULL in sgg_layernorm_hwc_elu_bwd DEFERS the parameter-gradient reductions (dgamma, dbeta, dbias_prev): the
  * partial sums stay in `workspace` (give every layer its own), and one launch of sgg_layernorm_hwc_bwd_finalize reduces up to 16

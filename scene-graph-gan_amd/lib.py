@@ -44,6 +44,7 @@ SIGNATURES = {
     "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 9 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_bwd_finalize": (_i, [_vp, _i, _vp]),
+    "sgg_layernorm_hwc_elu_bwd_status": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "sgg_layernorm_hwc_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -453,6 +454,17 @@ class HipKernels:
         self._check(self.lib.sgg_layernorm_hwc_bwd_finalize(ctypes.addressof(descs), len(descs), self._stream()),
                     "sgg_layernorm_hwc_bwd_finalize")
 
+    def ln_bwd_timed_out(self, shape, ws=None):
+        """True if the last ln_elu_bwd on this workspace (default: the shared one) gave up its bounded wait for a sample's partial
+        sums (sgg_layernorm_hwc_elu_bwd_status; synchronises)."""
+        B, H, W, C = shape
+        if ws is None:
+            ws = self.workspace(self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C))
+        flag = ctypes.c_int(0)
+        self._check(self.lib.sgg_layernorm_hwc_elu_bwd_status(_p(ws), B, H * W, C, ctypes.addressof(flag), self._stream()),
+                    "sgg_layernorm_hwc_elu_bwd_status")
+        return bool(flag.value)
+
     def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None, ws=None):
         """dgamma = dbeta = None with a workspace `ws` of the layer's own: the parameter-gradient reductions are deferred to
         ln_bwd_finalize."""
@@ -463,7 +475,8 @@ class HipKernels:
         if ws is None:
             ws = self.workspace(need)
         assert ws.numel() * ws.element_size() >= need
-        # algorithmic bytes: the reduction pass reads y and da, the apply pass reads them again and writes dy
+        # bytes of the two-pass form (the reduction reads y and da, the apply pass reads them again and writes dy); the one-pass
+        # kernel moves 3/5 of them
         self._check(self._timed("ln_elu_bwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_bwd(
             _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma), _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C,
             *self._region(region, H, W), _p(ws), ws.numel() * ws.element_size(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")
