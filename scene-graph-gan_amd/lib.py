@@ -157,6 +157,8 @@ class HipKernels:
         # (trunk._plan_ln_fusion: 28 of the 44 apply passes of a step at configs[1]); 2 = wherever the kernels allow (slower:
         # DESIGN.md); 0 = never
         self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "1"))
+        # A/B switch: 1 = layers whose forward applies an LN prologue also run the producer / consumer kernel (trunk._query_layouts)
+        self.halo_pc_ln_prologue = os.environ.get("SGG_HALO_PC_LNP", "0") == "1"
         self.ln_fusion_skip = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_SKIP", "").split(",") if v)   # A/B: conv indices
         self.ln_fusion_force = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_FORCE", "").split(",") if v)  # A/B: forward-only passes
         self.ln_fusion_force_bwd = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_FORCE_BWD", "").split(",") if v)  # A/B: passes with backward

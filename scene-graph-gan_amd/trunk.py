@@ -108,6 +108,7 @@ class Trunk:
             # 3x3 stride-1 layers on 8-divisible grids: halo-resident kernel, weights pre-arranged as MFMA fragments
             # (re-derived in refresh_weights: the layout depends on the conv precision in force)
             lay["hin"], lay["win"] = h, w
+            lay["prev"] = self.layers[-1] if self.layers else None
             # forward and dgrad are asked separately: the kernels' channel conditions are not symmetric in (cin, cout)
             lay["ws_layout"] = lay["ws_layout_bwd"] = 0
             self._query_layouts(lay)
@@ -157,9 +158,26 @@ class Trunk:
         if lay["cin"] != 3 and hasattr(K, "conv_wsplit_layout"):
             k, s = lay["k"], lay["s"]
             lay["ws_layout"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cin"], lay["cout"])
+            if lay["ws_layout"] == 4 and not getattr(K, "halo_pc_ln_prologue", False) and self._ln_prologue_expected(lay):
+                # The producer / consumer 3x3 kernel (layout 4) wins without the LayerNorm prologue (408-413 against 384 TFLOP/s in the
+                # step) and loses with it (337-345 against 358: its four producer waves carry all of the prologue's v_exp work beside one
+                # MFMA wave per SIMD).  A layer whose forward mostly runs with the prologue keeps the four-wave kernel's fragments for
+                # the forward; its dgrad (never a prologue) still takes layout 4 below.  
+                lay["ws_layout"] = 1
             ho, wo = lay["out_shape"][1], lay["out_shape"][2]
             # (both directions are asked with the full-resolution grid: forward input = dgrad output)
             lay["ws_layout_bwd"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cout"], lay["cin"])
+
+    def _ln_prologue_expected(self, lay):
+        """Will _plan_ln_fusion let this layer's forward apply the previous layer's LayerNorm + ELU in its patch staging, in either
+        kind of pass?  (The static part of that plan: the statistics conditions it adds can only remove a fusion.)"""
+        K, prev = self.K, lay.get("prev")
+        mode = getattr(K, "ln_fusion", 0)
+        if not mode or prev is None or not prev["has_ln"] or prev["region"] or not hasattr(K, "ln_prologue_ok"):
+            return False
+        if prev["i"] in getattr(K, "ln_fusion_skip", ()):
+            return False
+        return mode == 2 or any(ln_fusion_pays(prev["out_shape"], lay["cout"]))
 
     def _f16(self):
         return getattr(self.K, "conv_precision", 0) in (1, 2)      # fp16 pieces: per-tensor scaling from the amax words
