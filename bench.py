@@ -130,6 +130,7 @@ def conv_roofline(per, precision, dt):
          "flop_per_launch": fl / n, "share_of_step_time": sec / dt}
     targs = dom[dom.index("<") + 1:-1].split(",") if "<" in dom else []
     if (dom.startswith("conv_halo3_kernel") and len(targs) > 7 and targs[7] == "true") or \
+            (dom.startswith("conv_halo3_pc_kernel") and len(targs) > 1 and targs[1] == "true") or \
             (dom.startswith("conv_s2_kernel") and len(targs) > 4 and targs[4] == "true"):
         r["kernel_note"] = ("this instantiation also applies the producing layer's LayerNorm + ELU while staging its patches (LN prologue: "
                             "that work replaces a separate HBM pass and is not counted in `achieved`); the plain instantiation is in kernel_tflops_extra_steps")

@@ -323,9 +323,10 @@ class HipKernels:
     def halo_symbol(self, n_out, n_in, lnp=False):
         """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_halo.hip: sgg_halo_launch picks (default build)."""
         tile = "2,128,2,2" if n_out % 128 == 0 else ("2,64,2,2" if n_out % 64 == 0 else "2,32,2,1")
-        return "conv_halo3_kernel<%s,%s,%s,%s,%s,%s>" % (tile, "true" if self.conv_precision in (1, 2) else "false", "true",
-                                                         "true" if n_in == 32 else "false", "true" if lnp else "false",
-                                                         "true" if self.conv_precision in (1, 4) else "false")
+        # (last argument: blocks per wave, 1 in the default build - csrc/conv_halo.hip SGG_HALO_N128_WB2)
+        return "conv_halo3_kernel<%s,%s,%s,%s,%s,%s,1>" % (tile, "true" if self.conv_precision in (1, 2) else "false", "true",
+                                                           "true" if n_in == 32 else "false", "true" if lnp else "false",
+                                                           "true" if self.conv_precision in (1, 4) else "false")
 
     def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True, lnp=False):
         """(csrc/conv_s2.hip: 224-position bands; with at most 256 work items the channel chunks are split over two workgroups)"""
