@@ -155,6 +155,34 @@ def test_ln_prologue_schedule_matches_unfused(hip):
 
 
 @pytest.mark.gpu
+def test_step_runs_the_kernels_the_routing_names(hip):
+    """Which 3x3 kernels a whole G+D step launches for the 128-column layers (symbols as the library's own dispatch reports them to the
+    timing hook, i.e. the native path that ran): the producer / consumer kernel for every dgrad and every forward without LN prologue,
+    the four-wave kernel for forwards WITH the prologue (trunk._query_layouts), never the gather kernels on these shapes."""
+    B, S, V = 8, 64, 50
+    images, labels, _ = O.synth_batch(B, S, V)
+    noise0, noise1, alpha = O.synth_noise(B, 0), O.synth_noise(B, 1), O.synth_alpha(B, 0)
+    old = hip.ln_fusion
+    try:
+        hip.ln_fusion = 2       # (the default cost model fuses these layers at batch 64; 2 = wherever the kernels allow, also at batch 8)
+        gs = GanStep(hip, V, S, B, lam=10.0, g_state=O.init_params("G", V, S, perturb=0.05), d_state=O.init_params("D", V, S, perturb=0.05))
+        lay6 = gs.D.trunk.layers[6]
+        assert (lay6["cin"], lay6["cout"], lay6["ws_layout"], lay6["ws_layout_bwd"]) == (128, 128, 1, 4), lay6["ws_layout"]
+        hip.timing, hip.timing_conv_only, hip.timing_symbols = [], True, None
+        gs.critic_step(images.cuda(), labels.cuda(), noise0.cuda(), alpha.reshape(B).cuda())
+        gs.generator_step(images.cuda(), noise1.cuda())
+        gs.flush()
+        torch.cuda.synchronize()
+        syms = [t[0] for t in hip.timing]
+    finally:
+        hip.timing, hip.ln_fusion = None, old
+    count = lambda prefix: sum(s.startswith(prefix) for s in syms)
+    assert count("conv_halo3_pc_kernel<true,false>") >= 6, sorted(set(syms))          # dgrads of conv2_4, conv3_1, conv3_2 in both networks
+    assert count("conv_halo3_kernel<2,128,2,2,true,true,false,true,false,1>") >= 6, sorted(set(syms))     # LN-prologue forwards
+    assert count("conv_halo3_pc_kernel<true,true>") == 0 and count("conv_gather") == 0, sorted(set(syms))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ln_mode", [0, 2])
 def test_generator_encoder_reuse_within_iteration(hip, ln_mode):
     """train.py's loop (GanStep.iteration(reuse_g_encoder=True)): every update of an iteration sees the same minibatch and G's weights
