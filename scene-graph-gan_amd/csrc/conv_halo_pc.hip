@@ -13,10 +13,12 @@
 //     (buffer_load ... lds, no VGPRs, no VALU) into a ring of four 16-KiB tap slots shared by the four consumers (the L1 traffic of
 //     the weight operand halves, the consumers read it at LDS bandwidth), and the activation patch is staged two 32-channel chunks
 //     ahead (load, f32 -> 2 x fp16 split or the LayerNorm + ELU prologue, LDS write).
-// One raw s_barrier per tap (24 MFMAs per consumer) is the only synchronisation: behind barrier g the producers guarantee that the
+// One raw s_barrier per tap (48 MFMAs of 16x16x32 per consumer) is the only synchronisation: behind barrier g the producers guarantee that the
 // fragments of tap g+1 (and, at a chunk's last tap, the next patch) have landed, the consumers that they no longer read slot g.
 // Both roles run the SAME loop nest (tile, chunk, nine statically unrolled taps) with exactly one barrier per tap.
-// LDS: 2 patch buffers (61,440 B) + ring (65,536 B) + LayerNorm parameters (4 KB) of the 160 KB a gfx950 workgroup may use.
+// LDS: 2 patch buffers (61,440 B) + ring (65,536 B) (+ LayerNorm parameters, 4 KB) of the 160 KB a gfx950 workgroup may use.
+// Where it is used: every dgrad and every forward WITHOUT LN prologue of the 128-column layers; forwards with the prologue stay on
+// conv_halo3_kernel (sgg_amd/trunk.py: _query_layouts; measured in DESIGN.md section 3, "Round 3").
 #include "split16.h"
 #include "conv_halo.h"
 #include <type_traits>
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
 #pragma unroll
       for (int pp = 0; pp < PC_P; ++pp) rb[buf][j][pp] = *reinterpret_cast<const u32x4*>(o.bw + j * 2048 + pp * 1024);
   };
-  // MFMAs of row tiles 2 * half and 2 * half + 1 (24 instructions): hi * lo + lo * hi + hi * hi per (i, j)
+  // MFMAs of row tiles 2 * half and 2 * half + 1 (2 x 4 tiles x 3 = 24 instructions): hi * lo + lo * hi + hi * hi per (i, j)
   auto mma_half = [&](auto par_c, auto half_c) __attribute__((always_inline)) {
     constexpr int par = decltype(par_c)::value, half = decltype(half_c)::value;
 #pragma unroll

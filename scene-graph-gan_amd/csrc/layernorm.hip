@@ -571,7 +571,16 @@ __global__ __launch_bounds__(LNB_T, 4) void ln_bwd_fused_kernel(const float* __r
       seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ++polls;
     }
-    if (seen < G) __hip_atomic_store(ctr + LNB_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen < G) {
+      __hip_atomic_store(ctr + LNB_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SGG_LNB_DEBUG      // scripts/debug_lnb.py: who gave up first, and what it saw (the words behind the flag in the error line)
+      if (__hip_atomic_fetch_add(ctr + LNB_LINE + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        ctr[LNB_LINE + 2] = b; ctr[LNB_LINE + 3] = seen; ctr[LNB_LINE + 4] = ticket; ctr[LNB_LINE + 5] = G;
+        ctr[LNB_LINE + 6] = __hip_atomic_fetch_add(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctr[LNB_LINE + 7] = __hip_atomic_fetch_add(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#endif
+    }
   }
   __syncthreads();
   __atomic_signal_fence(__ATOMIC_SEQ_CST);

@@ -1,5 +1,7 @@
 """Debug aid: run training iterations with every ln_elu_bwd followed by a look at the one-pass kernel's counter lines
-(library built with -DSGG_LNB_DEBUG: SGG_HIP_LIB=.../libsgg_hip_lnbdbg.so)."""
+(bash scripts/build_variant_one.sh lnbdbg layernorm.hip -DSGG_LN_BWD_FUSED=1 -DSGG_LNB_DEBUG; SGG_HIP_LIB=.../_prof/libsgg_hip_lnbdbg.so).
+Error line words: flag, workgroups that gave up, then - from the first of them - sample, arrivals seen, own ticket, G, arrivals and
+tickets taken at that moment."""
 import os
 import sys
 
