@@ -48,9 +48,6 @@ void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st);
 // sgg_halo_launch dispatches to it when HaloParams::frag16 is set
 int sgg_halo_pc_applicable(int C, int N, int precision);
 void sgg_halo_pc_launch(const HaloParams& p, int precision, hipStream_t st);
-// the four-wave kernel on the K = 32 MFMA shape (conv_halo_k32.hip; same shapes and weight layout as the producer / consumer kernel):
-// sgg_halo_pc_launch hands it the launches with an LN prologue
-void sgg_halo_k32_launch(const HaloParams& p, int precision, hipStream_t st);
 
 // ---- halo-resident 3x3 stride-1 wgrad (conv_wgrad_halo.hip) ---------------------------------------------------
 struct WgradHaloPlan {

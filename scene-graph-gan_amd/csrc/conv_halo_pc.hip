@@ -504,20 +504,7 @@ int sgg_halo_pc_applicable(int C, int N, int precision) {
   return SGG_HALO_PC && (precision == 2 || precision == 3) && N % 128 == 0 && C % 64 == 0 && C <= 512;
 }
 
-// Launches WITH an LN prologue go to the four-wave kernel on the same MFMA shape and weight layout (conv_halo_k32.hip): this kernel's
-// producer waves lose 3 % there against conv_halo3_kernel.  -DSGG_HALO_LNP_K32=0: they stay here; -DSGG_HALO_K32_ALL=1: every
-// layout-4 launch takes the four-wave kernel (A/B builds).
-#ifndef SGG_HALO_LNP_K32
-#define SGG_HALO_LNP_K32 1
-#endif
-#ifndef SGG_HALO_K32_ALL
-#define SGG_HALO_K32_ALL 0
-#endif
 void sgg_halo_pc_launch(const HaloParams& p_, int precision, hipStream_t st) {
-  if (SGG_HALO_K32_ALL || (SGG_HALO_LNP_K32 && p_.ln_stats)) {
-    sgg_halo_k32_launch(p_, precision, st);
-    return;
-  }
   HaloParams p = p_;
   const int mtiles = sgg_cdiv(p.nblk, PC_NB), ntn = p.N / 128;
   int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       // (tile, n-tile) pairs an XCD owns

@@ -317,10 +317,8 @@ class HipKernels:
                                                        layout)
 
     def halo_pc_symbol(self, lnp=False):
-        """Kernel symbol of a w_split_layout-4 launch: the producer / consumer 3x3 kernel (csrc/conv_halo_pc.hip), or - with an LN
-        prologue - the four-wave kernel on the same MFMA shape (csrc/conv_halo_k32.hip; sgg_halo_pc_launch routes it)."""
-        half = "true" if self.conv_precision == 2 else "false"
-        return "conv_halo3_k32_kernel<%s,true>" % half if lnp else "conv_halo3_pc_kernel<%s,false>" % half
+        """Kernel symbol of the producer / consumer 3x3 kernel (csrc/conv_halo_pc.hip; w_split_layout 4)."""
+        return "conv_halo3_pc_kernel<%s,%s>" % ("true" if self.conv_precision == 2 else "false", "true" if lnp else "false")
 
     def halo_symbol(self, n_out, n_in, lnp=False):
         """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_halo.hip: sgg_halo_launch picks (default build)."""
