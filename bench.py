@@ -8,16 +8,21 @@ Default workload = BASELINE.json configs[1]: batch 64 per GPU, 224x224 synthetic
 (weak scaling: the global batch is 64*N, sharded by rows of one seeded global draw; the only exchange is the
 gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
 
-  value / ms_per_step   the timed region (default conv contraction mode, see DTYPE_NAME)
-  roofline              dominant convolution kernel against the MFMA peak (live HIP events around its launches in the timed region;
-                        which kernel that is comes from the last warm-up step, where every convolution launch is bracketed)
-  roofline_hbm          the memory-bound kernels (LSTM gates, attention, attention product, LayerNorm, Adam) against HBM peak,
-                        from HIP events around every such call in two extra steps of the same workload right after the timed
-                        region (the timed region itself brackets only the dominant kernel's launches: an event pair costs ~ 5 us, and
-                        ~ 230 pairs per step around every call would cost about 2 % of the headline); kernel_tflops_extra_steps holds
-                        the TFLOP/s of every other matrix kernel from the same two steps
+  value / ms_per_step   the timed region: the product's default schedule (train.py: two HIP streams - D's encoder beside G's forward,
+                        filter gradients beside the dgrad -> LayerNorm-backward chain; bit-identical to the serial order), default conv
+                        contraction mode (see DTYPE_NAME); config.schedule says so.  --single-stream times the serial order instead
+  serial                the same workload in the serial launch order, right after the timed region (kernels of two streams share the
+                        chip, so only serial steps give per-kernel durations): its steps bracket the dominant convolution kernel's launches
+  roofline              dominant convolution kernel against the MFMA peak (live HIP events around its launches in the `serial` steps;
+                        which kernel that is comes from one serial step before them, where every convolution launch is bracketed)
+  roofline_hbm          the memory-bound kernels (conv1_1, LSTM gates, attention, attention product, LayerNorm, Adam) against HBM peak,
+                        from HIP events around every such call in two extra serial steps (the `serial` steps bracket only the dominant
+                        kernel's launches: an event pair costs ~ 5 us); kernel_tflops_extra_steps holds the TFLOP/s of every other
+                        matrix kernel from the same two steps
   native_f32            the same workload re-timed in the same run with native f32 MFMA arithmetic (mode 0)
   parity                same-run checks: default mode vs native f32 (logits, tokens) and both vs the CPU oracle
+  other_configs         (N = 1, default workload only) short legs of the other single-GPU configs of BASELINE.json - configs[3] (vocab
+                        70 000) and configs[4] (batch 32, 448x448) -: value, ms_per_step, default mode vs native f32 on logits / tokens
   critic_iters_10       secondary line: the loop body with the reference flag's nominal CRITIC_ITERS = 10 (train.py:408)
   cpu_baseline          the CPU oracle timed on this box's host cores (same run, N = 1 only)
   rccl                  (N > 1) what the collective layer saw and how much of the all-reduce is exposed
@@ -225,16 +230,14 @@ def self_launch(n):
     process per GPU, the command line the driver itself uses) and relay rank 0's JSON line and the child's exit code.  This
     process never touches the GPU (no HIP call, no torch.cuda.is_available()) and never replaces itself (no os.exec*): the
     reference selects one device per process (train.py:417-418); the N-process layout is this build's."""
-    import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous on a port the OS picks when it binds (no pre-picked port that another
+    # bench started at the same moment could take); --local-addr: the container hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           os.path.abspath(__file__)] + sys.argv[1:]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     js = [l for l in lines if l.lstrip().startswith("{")]
@@ -247,7 +250,19 @@ def self_launch(n):
     elif r.returncode == 0:
         print("bench.py: the %d-rank child printed no JSON line" % n, file=sys.stderr)
         return 1
-    return r.returncode
+    return exit_code_from(r.returncode, js[-1] if js else None)
+
+
+def exit_code_from(child_rc, line):
+    """torch.distributed.run collapses any rank failure to exit code 1, so the parity verdict travels in the JSON line: 3 when rank 0
+    printed a line whose same-run parity record is not ok (the code a single-process run returns itself), else the child's own."""
+    if line is not None:
+        try:
+            if json.loads(line).get("parity", {}).get("ok") is False:
+                return 3
+        except ValueError:
+            pass
+    return child_rc
 
 
 def rendezvous_only(args):
@@ -278,6 +293,56 @@ def rendezvous_only(args):
     return 0 if ok else 1
 
 
+def other_config_leg(K, cfg, steps, warmup=1):
+    """A short leg of another single-GPU config of BASELINE.json on the product's default schedule: `steps` timed G+D steps, then the
+    generator's logits / tokens in the default arithmetic against native f32 MFMA on the same weights.  No CPU leg.  The networks are
+    built here and freed on return."""
+    from sgg_amd.params import init_state_dict
+    from sgg_amd.step import GanStep
+    B, S, V = CONFIGS[cfg]
+    dev = K.device
+    gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), overlap_streams=True)
+    images, labels, noises, alphas = synth_inputs(B, S, V, 2 * (warmup + steps), 0, 1, dev)
+
+    def one(k):
+        gs.critic_step(images, labels, noises[2 * k], alphas[2 * k])
+        gs.generator_step(images, noises[2 * k + 1])
+    for k in range(warmup):
+        one(k)
+    gs.flush()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        one(k)
+    gs.flush()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    rec = {"workload": workload_name(B, S, V, 1), "value": B * steps / dt, "unit": "triples/sec", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps, "schedule": "two-stream", "conv_tflops_whole_step": conv_flops_per_step(B, S) * steps / dt / 1e12}
+    main_prec = K.conv_precision
+    if main_prec != 0:
+        from oracle import sgg_oracle as O          # (top-2 margin helper only: the checker, never the thing measured)
+        st, _ = gs.generator_forward(images, noises[0])
+        logits_main = st.OUT[0].clone()
+        toks_main = gs.argmax_tokens(logits_main).clone()
+        try:
+            K.conv_precision = 0
+            gs.G.trunk.refresh_weights()
+            st, _ = gs.generator_forward(images, noises[0])
+            logits_f32 = st.OUT[0].clone()
+            toks_f32 = gs.argmax_tokens(logits_f32).clone()
+        finally:
+            K.conv_precision = main_prec
+        err, margin = float((logits_main - logits_f32).abs().max()), O.top2_margin(logits_f32.cpu())
+        equal = bool(torch.equal(toks_main, toks_f32))
+        rec["parity"] = {"mode%d_vs_native_f32" % main_prec: {"max_logit_err": err, "max_abs_logit": float(logits_f32.abs().max()),
+                                                             "tokens_equal": equal, "top2_logit_margin": margin},
+                         "ok": bool(err <= 1e-4 + 1e-4 * float(logits_f32.abs().max()) and (equal or margin < 8.0 * err))}
+    del gs
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,14 +355,17 @@ def main():
     ap.add_argument("--critic-iters", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the cpu_baseline / oracle-parity step (0 = skip; default: the "
                                                                "whole per-GPU batch up to 224x224, 16 rows at 448x448)")
-    ap.add_argument("--f32-steps", type=int, default=3, help="steps of the native-f32 leg (0 = skip)")
+    ap.add_argument("--f32-steps", type=int, default=10, help="steps of the native-f32 leg (0 = skip)")
     ap.add_argument("--ci10-steps", type=int, default=2, help="iterations of the critic_iters = 10 secondary leg (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--per-shape", action="store_true", help="add per-layer conv timings to the JSON line")
-    ap.add_argument("--two-stream-steps", type=int, default=5, help="steps of the secondary two-stream leg (0 = skip)")
-    ap.add_argument("--overlap-streams", action="store_true",
-                    help="time the two-stream schedule itself (D's encoder beside G's forward, filter gradients beside dgrad + LayerNorm "
-                         "backward: +4 %%; per-kernel event durations are then no roofline evidence)")
+    ap.add_argument("--per-shape", action="store_true", help="add per-layer conv timings (from the serial steps) to the JSON line")
+    ap.add_argument("--serial-steps", type=int, default=5,
+                    help="steps of the serial-order leg that follows the timed region; `roofline` is measured in them (0 = skip: no roofline)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="time the serial launch order as the headline (default: the product's two-stream schedule; per-kernel event "
+                         "durations always come from serial steps, where no two kernels share the chip)")
+    ap.add_argument("--other-configs", type=int, default=5,
+                    help="timed steps of the configs[3] / configs[4] legs appended to the default workload's line at N = 1 (0 = skip)")
     ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 1, 2, 3, 4, 6],
                     help="conv contraction: 2 = scaled fp16 pieces, 3 products (default), 6 = bf16 pieces, 6 products, "
                          "0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance); 1 / 4 = ONE fp16 / bf16 piece, one product "
@@ -335,12 +403,21 @@ def main():
     S = args.size if args.size is not None else S0
     V = args.vocab if args.vocab is not None else V0
     CI = args.critic_iters
+    two_stream = not args.single_stream
     reducer = dpmod.GradReducer() if world > 1 else None
     gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer,
-                 overlap_streams=args.overlap_streams, head_side_stream=args.head_side_stream)
-    extra = 2 + (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0) + (args.two_stream_steps + 1)
+                 overlap_streams=two_stream, head_side_stream=args.head_side_stream)
+    side_stream = gs.side
+    kt = not args.no_kernel_timing
+    extra = (args.serial_steps + 2) + (2 if kt else 0) + (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0)
     total_steps = args.warmup + args.steps
     images, labels, noises, alphas = synth_inputs(B * world, S, V, (total_steps + extra) * (CI + 1), rank, world, dev)
+
+    def set_schedule(two):
+        """Two-stream (the product's default, GanStep(overlap_streams=True)) or serial launch order; same kernels, same results."""
+        gs.side = side_stream if two else None
+        gs.G.trunk.enable_wgrad_overlap(gs.side)
+        gs.D.trunk.enable_wgrad_overlap(gs.side)
 
     def one_step(k):
         base = k * (CI + 1)
@@ -372,74 +449,87 @@ def main():
             dt = float(t.item())
         return dt, timing
 
-    # The LAST warm-up step brackets every forward / dgrad convolution launch with HIP events and names the dominant kernel (largest
-    # summed duration); the timed steps then bracket only that kernel's launches (an event pair costs ~ 5 us of the timed region).
-    kt = not args.no_kernel_timing
-    dominant = None
+    # ---- the timed region: W warm-up steps, then exactly K steps of the product's default schedule, no event inside -------------
     for k in range(args.warmup):
-        last = kt and not args.per_shape and k == args.warmup - 1
-        if last:
+        one_step(k)
+    gs.flush()
+    dt, _ = timed(args.warmup, args.steps, False)
+    d_losses, g_losses = gs.d_losses.cpu().tolist(), gs.g_losses.cpu().tolist()
+    next_k = total_steps
+
+    # ---- the same workload in the serial launch order: per-kernel durations (kernels of two streams would share the chip).  One
+    # step brackets every forward / dgrad convolution launch and names the dominant kernel (largest summed duration); the serial
+    # steps then bracket only that kernel's launches (an event pair costs ~ 5 us); two more steps bracket every call.
+    dt_ser, timing, timing_hbm, hbm_steps, dominant = None, None, None, 2, None
+    if args.serial_steps > 0:
+        set_schedule(False)
+        if kt:
             torch.cuda.synchronize(dev)
             K.timing, K.timing_conv_only, K.timing_symbols = [], True, None
-        one_step(k)
-        if last:
-            gs.flush()
+        one_step(next_k)
+        gs.flush()
+        if kt:
             torch.cuda.synchronize(dev)
             wt, K.timing = K.timing, None
             per_w = summarise_timing(wt)
-            conv_w = [s for s in per_w if s.startswith(("conv_gather", "conv_halo", "conv_s2"))]
-            dominant = max(conv_w, key=lambda s: per_w[s][3]) if conv_w else None
-    gs.flush()
-    K.timing_symbols = {dominant} if dominant else None
-    dt, timing = timed(args.warmup, args.steps, kt, conv_only="mfma" if args.per_shape else True)
-    K.timing_symbols = None
-    d_losses, g_losses = gs.d_losses.cpu().tolist(), gs.g_losses.cpu().tolist()
-    next_k = total_steps
-    timing_hbm, hbm_steps = None, 2
-    if not args.no_kernel_timing:
-        _, timing_hbm = timed(next_k, hbm_steps, True, conv_only=False)
-        next_k += hbm_steps
+            conv_w = [s_ for s_ in per_w if s_.startswith(("conv_gather", "conv_halo", "conv_s2"))]
+            dominant = max(conv_w, key=lambda s_: per_w[s_][3]) if conv_w else None
+            K.timing_symbols = {dominant} if (dominant and not args.per_shape) else None
+        dt_ser, timing = timed(next_k + 1, args.serial_steps, kt, conv_only="mfma" if args.per_shape else True)
+        K.timing_symbols = None
+        next_k += args.serial_steps + 1
+        if kt:
+            _, timing_hbm = timed(next_k, hbm_steps, True, conv_only=False)
+            next_k += hbm_steps
+        set_schedule(two_stream)
 
     out = None
     if rank == 0:
         value = B * world * args.steps / dt
+        sched = ("two-stream; per-kernel figures from serial steps" if two_stream else "serial (--single-stream)")
         out = {
             "metric": "triples/sec (G+D step)", "value": value, "unit": "triples/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NAME[K.conv_precision], "data": "synthetic",
             "config": {"workload": workload_name(B, S, V, CI), "global_batch": B * world, "critic_iters": CI,
-                       "parallelism": "dp%d" % world, "conv_precision_mode": K.conv_precision},
+                       "parallelism": "dp%d" % world, "conv_precision_mode": K.conv_precision, "schedule": sched},
             "losses": {"disc_cost": d_losses[0], "gp": d_losses[2], "gen_cost": -g_losses[3]},
         }
         flops_step = conv_flops_per_step(B, S) * (CI + 1) / 2.0 if CI == 1 else None
         if flops_step:
             out["conv_tflops_whole_step_per_gpu"] = flops_step * args.steps / dt / 1e12
+        if dt_ser is not None:
+            out["serial"] = {"value": B * world * args.serial_steps / dt_ser, "unit": "triples/sec", "steps": args.serial_steps,
+                             "ms_per_step": 1e3 * dt_ser / args.serial_steps,
+                             "schedule": "serial launch order (one HIP stream): same kernels, same results; `roofline` is measured here"}
         if timing:
             per = summarise_timing(timing)
-            out["roofline"] = conv_roofline(per, K.conv_precision, dt)
+            out["roofline"] = conv_roofline(per, K.conv_precision, dt_ser)
+            out["roofline"]["measured_in"] = "the `serial` leg (%d steps, %.2f ms per step)" % (args.serial_steps, 1e3 * dt_ser / args.serial_steps)
+            out["roofline"]["launches_per_step"] = out["roofline"]["launches"] / args.serial_steps
             out["roofline_hbm"] = hbm_rooflines(summarise_timing(timing_hbm), hbm_steps)
-            out["kernel_time_s"] = {s: round(v[3], 4) for s, v in sorted(per.items(), key=lambda kv: -kv[1][3])}
-            out["kernel_tflops"] = {s: round(v[1] / v[3] / 1e12, 2) for s, v in per.items() if v[3] > 0 and v[1] > 0}
+            out["kernel_time_s"] = {s_: round(v[3], 4) for s_, v in sorted(per.items(), key=lambda kv: -kv[1][3])}
+            out["kernel_tflops"] = {s_: round(v[1] / v[3] / 1e12, 2) for s_, v in per.items() if v[3] > 0 and v[1] > 0}
             # every other matrix kernel (the other convolution instantiations, filter gradients, conv1_1, attention product) is
             # bracketed in the two extra steps only
             per_x = summarise_timing(timing_hbm)
-            out["kernel_tflops_extra_steps"] = {s: round(v[1] / v[3] / 1e12, 2) for s, v in per_x.items()
-                                                if v[3] > 0 and v[1] > 0 and s not in per}
+            out["kernel_tflops_extra_steps"] = {s_: round(v[1] / v[3] / 1e12, 2) for s_, v in per_x.items()
+                                                if v[3] > 0 and v[1] > 0 and s_ not in per}
             if dominant:
-                conv_x = {s: v[3] for s, v in per_x.items() if s.startswith(("conv_gather", "conv_halo", "conv_s2"))}
-                out["roofline"]["dominant_selected_in"] = ("the last warm-up step (every forward / dgrad convolution launch bracketed); "
-                                                           "largest summed duration in the extra steps: %s" % max(conv_x, key=conv_x.get))
+                conv_x = {s_: v[3] for s_, v in per_x.items() if s_.startswith(("conv_gather", "conv_halo", "conv_s2"))}
+                out["roofline"]["dominant_selected_in"] = ("one serial step before the `serial` leg (every forward / dgrad convolution launch "
+                                                           "bracketed); largest summed duration in the extra steps: %s" % max(conv_x, key=conv_x.get))
             if args.per_shape:     # per (kernel, FLOPs per launch) = per layer and direction
                 shp = {}
                 for sym, fl, nb, e0, e1 in timing:
                     if fl <= 0:
                         continue
-                    a = shp.setdefault("%s @ %.1f GF" % (sym, fl / 1e9), [0, 0.0])
-                    a[0] += 1
-                    a[1] += e0.elapsed_time(e1) * 1e-3
-                out["per_shape"] = {k: {"launches": v[0], "ms_per_step": round(1e3 * v[1] / args.steps, 3),
-                                        "tflops": round(float(k.split("@")[1].split()[0]) * 1e9 * v[0] / v[1] / 1e12, 1)}
-                                    for k, v in sorted(shp.items(), key=lambda kv: -kv[1][1])}
+                    a_ = shp.setdefault("%s @ %.1f GF" % (sym, fl / 1e9), [0, 0.0])
+                    a_[0] += 1
+                    a_[1] += e0.elapsed_time(e1) * 1e-3
+                out["per_shape"] = {k_: {"launches": v[0], "ms_per_step": round(1e3 * v[1] / args.serial_steps, 3),
+                                         "tflops": round(float(k_.split("@")[1].split()[0]) * 1e9 * v[0] / v[1] / 1e12, 1)}
+                                    for k_, v in sorted(shp.items(), key=lambda kv: -kv[1][1])}
 
     # ---- N > 1: what RCCL saw, and how much of the gradient all-reduce is exposed (same ranks, reducer off) --------------
     if world > 1:
@@ -455,25 +545,7 @@ def main():
                            "allreduce_bytes_per_step": 4 * (gs.G.arena.live_numel + CI * gs.D.arena.live_numel),
                            "ms_per_step_without_allreduce": ms_off, "allreduce_ms_exposed": ms_on - ms_off}
 
-    # ---- the same workload on the two-stream schedule (GanStep(overlap_streams=True): D's encoder beside G's forward, filter
-    # gradients beside the dgrad -> LayerNorm-backward chain; bit-identical results, tests/test_concurrency_gpu.py).  Not the
-    # headline: concurrent kernels make the per-kernel event durations of `roofline` meaningless, so the timed region is serial.
-    if not args.overlap_streams and args.two_stream_steps > 0:
-        gs.side = torch.cuda.Stream(device=dev)
-        gs.G.trunk.enable_wgrad_overlap(gs.side)
-        gs.D.trunk.enable_wgrad_overlap(gs.side)
-        one_step(next_k)
-        dt2, _ = timed(next_k + 1, args.two_stream_steps, False)
-        next_k += args.two_stream_steps + 1
-        gs.side = None
-        gs.G.trunk.enable_wgrad_overlap(None)
-        gs.D.trunk.enable_wgrad_overlap(None)
-        if rank == 0:
-            out["two_stream"] = {"value": B * world * args.two_stream_steps / dt2, "unit": "triples/sec", "steps": args.two_stream_steps,
-                                 "ms_per_step": 1e3 * dt2 / args.two_stream_steps,
-                                 "schedule": "--overlap-streams: same kernels, same results, independent launches on a second HIP stream"}
-
-    # ---- the same workload in native f32 MFMA arithmetic, same run (the reference arithmetic is IEEE fp32) -----------------
+    # ---- the same workload in native f32 MFMA arithmetic, same run, same schedule (the reference arithmetic is IEEE fp32) ------
     if K.conv_precision != 0 and args.f32_steps > 0:
         main_prec = K.conv_precision
         st, _ = gs.generator_forward(images, noises[0])
@@ -486,13 +558,19 @@ def main():
         logits_f32 = st.OUT[0].clone()
         toks_f32 = gs.argmax_tokens(logits_f32).clone()
         one_step(next_k)
-        dt32, timing32 = timed(next_k + 1, args.f32_steps, not args.no_kernel_timing)
+        dt32, _ = timed(next_k + 1, args.f32_steps, False)
+        next_k += args.f32_steps + 1
+        timing32 = None
+        if kt:      # its own roofline from two serial steps with every forward / dgrad convolution launch bracketed
+            set_schedule(False)
+            _, timing32 = timed(next_k - 2, 2, True, conv_only=True)
+            set_schedule(two_stream)
         K.conv_precision = main_prec
         gs.G.trunk.refresh_weights()
         gs.D.trunk.refresh_weights()
         if rank == 0:
             out["native_f32"] = {"value": B * world * args.f32_steps / dt32, "unit": "triples/sec", "steps": args.f32_steps,
-                                 "ms_per_step": 1e3 * dt32 / args.f32_steps, "dtype": DTYPE_NAME[0]}
+                                 "ms_per_step": 1e3 * dt32 / args.f32_steps, "dtype": DTYPE_NAME[0], "schedule": out["config"]["schedule"]}
             if timing32:
                 out["native_f32"]["roofline"] = conv_roofline(summarise_timing(timing32), 0, dt32)
             from oracle import sgg_oracle as O
@@ -528,6 +606,9 @@ def main():
     rc = 0
     if rank == 0:
         rows = args.cpu_rows if args.cpu_rows is not None else (B if S <= 224 else min(B, 16))
+        default_workload = (B, S, V, CI) == CONFIGS[1] + (1,)
+        del gs
+        torch.cuda.empty_cache()
         if world == 1 and rows > 0:
             try:
                 ncpu = len(os.sched_getaffinity(0))
@@ -537,6 +618,9 @@ def main():
             cpu, par = parity_and_cpu_baseline(K, S, V, rows, min(ncpu, 16), precs)   # a 1-GPU box grants 16 host cores
             out["cpu_baseline"] = cpu
             out.setdefault("parity", {}).update(par)
+        # ---- the other single-GPU configs of BASELINE.json, observed in the same line (networks built and freed one after the other) --
+        if world == 1 and default_workload and args.other_configs > 0:
+            out["other_configs"] = {"configs[%d]" % c: other_config_leg(K, c, args.other_configs) for c in (3, 4)}
         # same-run parity is ENFORCED: the line is printed either way, the exit code says whether the
         # arithmetic mode that was timed agrees with the oracle (and with native f32 on the timed workload's tokens)
         par = out.get("parity")
@@ -548,6 +632,7 @@ def main():
                 r = par[k]
                 r["ok"] = bool(r["tokens_equal"] or r["top2_logit_margin"] < 8.0 * r["max_logit_err"])
                 checks.append(r["ok"])
+            checks += [leg["parity"]["ok"] for leg in out.get("other_configs", {}).values() if "parity" in leg]
             par["ok"] = bool(all(checks))
             head = par.get("precision%d_vs_oracle" % K.conv_precision)
             if (head is not None and not head["ok"]) or not all(par[k]["ok"] for k in par if k.endswith("_vs_native_f32")):

@@ -63,7 +63,7 @@ int sgg_absmax(const float* x, long long n, float* amax /* atomically max-ed; ze
  * Producer / consumer kernel for the 3x3 stride-1 layers with 128-column tiles (generator_with_attention.py:44-57: conv2_3,
  * conv2_4, conv3_1, conv3_2 forward; conv2_4, conv3_1, conv3_2 dgrad): where a layout-1 layer also has Cout % 128 == 0 and
  * Cin % 64 == 0 in precision 2 / 3, sgg_conv_wsplit_layout returns 4 instead - one 8-wave workgroup per CU (4 MFMA waves on
- * v_mfma_f32_16x16x32_*, 2 weight-DMA waves, 2 patch-staging waves; csrc/conv_halo_pc.hip); the pre-split weights are then the
+ * v_mfma_f32_16x16x32_*, 4 producer waves that each DMA a quarter of every tap's weight fragments and stage a quarter of the patch; csrc/conv_halo_pc.hip); the pre-split weights are then the
  * fragments of THAT MFMA shape (sgg_conv_split_weights_frag16) and w_split_layout = 4 is passed to sgg_conv2d_nhwc_fwd / _dgrad.
  * Same arithmetic as layout 1 (same pieces, same three products per f32 product, f32 accumulation; the order of the sum over the
  * 32 channels of a chunk differs). */
@@ -136,12 +136,6 @@ int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamm
                               const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
                               float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* workspace,
                               size_t workspace_bytes, void* stream);
-/* Builds with -DSGG_LN_BWD_FUSED=1 (not the default: measured equal, profiles/r03_ln_bwd_one_pass.log) run sgg_layernorm_hwc_elu_bwd
- * as ONE kernel that reads y and da once where a sample splits into at most 128 pieces of 16384 elements: a workgroup holds its
- * piece in registers while the two sums over the sample are exchanged between workgroups.  That wait is bounded; *timed_out = 1
- * reports that the last call on `workspace` gave up on it (dy of that call is then not valid).  Always 0 in the default build.
- * Synchronises with `stream`: an aid for tests, not part of the training step. */
-int sgg_layernorm_hwc_elu_bwd_status(const void* workspace, int B, int HW, int C, int* timed_out, void* stream);
 
 /* dgamma == dbeta == NULL in sgg_layernorm_hwc_elu_bwd DEFERS the parameter-gradient reductions (dgamma, dbeta, dbias_prev): the
  * partial sums stay in `workspace` (give every layer its own), and one launch of sgg_layernorm_hwc_bwd_finalize reduces up to 16

@@ -1,6 +1,7 @@
-"""Host-side mirror of the reference's model classes (shared by architectures/*.py): lazily builds the network for
-the first (batch, image size) it sees, shares weights across builds (tf.AUTO_REUSE, train.py:86,91) and exposes the
-attributes the reference sets on `self` (generator_with_attention.py:16,68,74,75)."""
+"""Host-side mirror of the reference's model classes (shared by architectures/*.py): lazily builds the network for the
+image size it first sees and for every batch size it is called with, shares ONE set of weights across all builds
+(tf.AUTO_REUSE, train.py:86,91) and exposes the attributes the reference sets on `self`
+(generator_with_attention.py:16,68,74,75)."""
 from __future__ import annotations
 
 import torch
@@ -25,13 +26,17 @@ def kernels_for(device):
 class NetworkHandle(object):
     def __init__(self, kind, vocab_size):
         self.kind, self.vocab_size = kind, int(vocab_size)
-        self.net = None
+        self.net = None              # the network of the first batch size seen (owner of the parameter arenas)
+        self._nets = {}              # batch size -> Network sharing those arenas
+        self._last = None            # the network of the most recent build (attention / attributes refer to it)
         self.embedding_matrix = None
         self.init_seed = 3
 
     def _ensure(self, images):
-        """Create the network (parameters with the reference's initialisers) on first use; later calls must use
-        the same static shape (the reference also needs a static spatial size, generator_with_attention.py:15)."""
+        """The network for this batch size, created on first use.  The variables (parameters with the reference's initialisers,
+        gradient and Adam slots) exist once; every batch size gets activation buffers of its own on top of them - the reference
+        graph is batch-dynamic (generator_with_attention.py:74-75) and serves B, B/2 and B/2 x 8 rows (train.py:29-30, 199-203,
+        297-298).  The spatial size is static, as in the reference (generator_with_attention.py:15 reads it from get_shape())."""
         assert images.dim() == 4 and images.shape[3] == 3 and images.shape[1] == images.shape[2], "images must be NHWC [B,S,S,3]"
         B, S = int(images.shape[0]), int(images.shape[1])
         if self.net is None:
@@ -41,11 +46,18 @@ class NetworkHandle(object):
             if self.kind == "D" and self.embedding_matrix is not None:
                 sd["W"] = torch.as_tensor(self.embedding_matrix).detach().float().cpu()
             self.net = Network(K, self.kind, self.vocab_size, S, B, E, state_dict=sd)
+            self._nets[B] = self.net
             if self.kind == "D":
                 self.embedding_matrix = self.net.arena.views["W"]
-        if (self.net.trunk.B, self.net.trunk.S) != (B, S):
-            raise ValueError("network was built for batch %d, size %d; got %d, %d" % (self.net.trunk.B, self.net.trunk.S, B, S))
-        return self.net
+        if self.net.trunk.S != S:
+            raise ValueError("network was built for %dx%d images; got %dx%d (the attention weights depend on the feature-map size)"
+                             % (self.net.trunk.S, self.net.trunk.S, S, S))
+        net = self._nets.get(B)
+        if net is None:
+            net = self._nets[B] = Network(self.net.K, self.kind, self.vocab_size, S, B, self.net.arena.E, share=self.net)
+        net.finish_update()          # (a deferred optimiser step of a data-parallel run is applied before the weights are read)
+        self._last = net
+        return net
 
     def _publish(self, ctx, st):
         B, L = ctx.shape[0], ctx.shape[1]
@@ -58,7 +70,7 @@ class NetworkHandle(object):
 
     def _attention(self, cell_state):
         """attentionMechanism: z_hat for an arbitrary (c, h) state on the current feature map."""
-        net, ctx = self.net, self._ctx
+        net, ctx = self._last, self._ctx
         B, L = ctx.shape[0], ctx.shape[1]
         c = cell_state[0].contiguous()
         K = net.K

@@ -50,7 +50,8 @@ def _compile(src):
     return obj, err
 
 
-OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib", "llvm", "bin",
+                                                      "llvm-objdump"))
 
 
 def check_no_packed_fp32(lib_path: str = LIB_PATH) -> int:
@@ -66,6 +67,9 @@ def check_no_packed_fp32(lib_path: str = LIB_PATH) -> int:
     os.makedirs(tmp)
     copy = os.path.join(tmp, "lib.so")
     shutil.copy(lib_path, copy)
+    if not os.path.exists(OBJDUMP):
+        raise RuntimeError("llvm-objdump not found at %s (set LLVM_OBJDUMP): the build cannot verify that the library is free of "
+                           "packed-fp32 VALU instructions" % OBJDUMP)
     r = subprocess.run([OBJDUMP, "--offloading", copy], capture_output=True, text=True)     # writes lib.so.<i>.<triple> next to `copy`
     if r.returncode != 0:
         raise RuntimeError("llvm-objdump --offloading failed:\n%s" % r.stderr)

@@ -791,7 +791,9 @@ extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout,
   if (precision == 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
   if (w_split_layout == 1 || w_split_layout == 4) {
     if (!sgg_halo_applicable(KH, KW, stride, Ho, Wo, Cin, Cout, precision)) return 0;
-    return (Ho * Wo / 64) * (Cout / sgg_halo_stats_cols(Cout));
+    // (the producer / consumer kernel of layout 4 always emits one partial per block and 64 columns, whatever tiling the
+    // four-wave kernel was built with)
+    return (Ho * Wo / 64) * (Cout / (w_split_layout == 4 ? 64 : sgg_halo_stats_cols(Cout)));
   }
   if (w_split_layout == 2) {
     if (!sgg_s2_applicable(KH, KW, stride, 1, 2 * Ho, 2 * Wo, Cin, Cout, precision)) return 0;

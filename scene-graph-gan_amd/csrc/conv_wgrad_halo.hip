@@ -24,6 +24,15 @@
 #include "conv_halo.h"
 #include <type_traits>
 
+// Timing-only ablations (wrong results by design; scripts/build_variant_one.sh): SGG_WABL_NOSPLIT = the staged bytes go to LDS as
+// they are (what pre-split 16-bit operand planes in HBM would leave of the staging: loads + LDS writes, no arithmetic);
+// SGG_WABL_NOSTAGE = nothing is loaded or written after the first stage (MFMAs, LDS reads and barriers only).
+#ifndef SGG_WABL_NOSPLIT
+#define SGG_WABL_NOSPLIT 0
+#endif
+#ifndef SGG_WABL_NOSTAGE
+#define SGG_WABL_NOSTAGE 0
+#endif
 typedef short s16x4h __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
 
@@ -277,7 +286,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
         }
       }
       u32x4 pl[P];
+#if SGG_WABL_NOSPLIT
+      pl[0] = __builtin_bit_cast(u32x4, pre[j][0]);
+      if constexpr (P == 2) pl[1] = __builtin_bit_cast(u32x4, pre[j][1]);
+#else
       split8<P, HALF>(pre[j][0], pre[j][1], isx ? sa : sb, pl);
+#endif
       if ((it_lds[j] >> 24) & 1) {
         unsigned char* dst = (isx ? x_s : d_s) + (it_lds[j] & 0xfffff);
 #pragma unroll
@@ -406,15 +420,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int s = 0; s < p.stages; ++s) {
+#if !SGG_WABL_NOSTAGE
     if constexpr (PREF) stage_load();        // next stage's blocks (out-of-range offsets past the end: zeros, no traffic)
+#endif
     __builtin_amdgcn_sched_barrier(0);
     SGG_PRIO_HI();
     compute();
     SGG_PRIO_LO();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if !SGG_WABL_NOSTAGE
     if constexpr (!PREF) stage_load();
     stage_write();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }

@@ -11,6 +11,13 @@
 // (unaligned operands take a scalar load path).
 #include "mma_f32.h"
 #include <stdlib.h>
+#include <type_traits>
+
+// 1: the head GEMMs whose 64 x 64 tiling would split K over workgroups run on gemm_wk_kernel (split over the waves of one
+// workgroup, no slabs, one launch); 0 (-DSGG_GEMM_WK=0): always the slab kernels
+#ifndef SGG_GEMM_WK
+#define SGG_GEMM_WK 1
+#endif
 
 struct GemmParams {
   const float* A;
@@ -159,6 +166,125 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_wide_kernel(const float*
   }
 }
 
+// ---- split-K INSIDE one workgroup (NN and NT of the recurrent heads) --------------------------------------------------------
+// The head GEMMs have M = 64 .. 192 rows and K = 196 .. 2048: with 64 x 64 tiles they are a handful of tiles, so the kernel above
+// splits K over workgroups, writes f32 partial slabs and a second launch sums them - two dependent launches and a slab round trip
+// per GEMM, ~100 reduce launches per G+D step, on the critical path of the LSTM step chains.  Here a workgroup OWNS its output tile
+// for the whole of K and the split is over its 8 WAVES:
+//   * tile = (16 TM) rows x 16 columns on v_mfma_f32_16x16x4_f32 (same FLOPs per cycle as 32x32x2; the 16-column tile is what gives
+//     N / 16 x M / (16 TM) >= 200 workgroups for these shapes: TM is chosen per call so that the grid fills the 256 CUs);
+//   * wave w takes every k in [16 g_w, 16 g_{w+1}) (a balanced partition of the 16-deep k groups); operands go global -> registers
+//     directly, 16 bytes per lane along k where k is the contiguous dimension (A always; B in NT), PD groups in flight per wave;
+//     lane l = (q, i) = (l >> 4, l & 15) loads k = kb + 4 q .. + 3 and feeds element jj to MFMA jj, which then contracts
+//     k = {kb + jj, kb + 4 + jj, kb + 8 + jj, kb + 12 + jj} - the same permutation for A and B, so the sum is unchanged;
+//   * the 8 partial accumulators are summed through LDS in wave order (deterministic), bias / accumulate applied, ONE store.
+// Rows / columns past M / N are clamped on load (finite values, never stored); k past K loads zeros.
+#define WK_WAVES 8
+template <int TM, bool TB, int PD>
+__global__ __launch_bounds__(64 * WK_WAVES, 4) void gemm_wk_kernel(GemmParams p) {
+  __shared__ float red[WK_WAVES * TM * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int mtiles = (p.M + 16 * TM - 1) / (16 * TM);
+  const int ntiles = (p.N + 15) / 16;
+  const int bid = xcd_remap(blockIdx.x, mtiles * ntiles);       // consecutive ids share an XCD: the m-tiles of one weight slab
+  const int m0 = (bid % mtiles) * 16 * TM, n0 = (bid / mtiles) * 16;
+  const int ngroups = (p.K + 15) >> 4;
+  const int g0 = (wave * ngroups) / WK_WAVES, g1 = ((wave + 1) * ngroups) / WK_WAVES;
+
+  const float* arow[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) arow[tm] = p.A + (size_t)min(m0 + tm * 16 + i, p.M - 1) * p.lda;
+  const int ncol = min(n0 + i, p.N - 1);
+  const float* bptr = TB ? p.B + (size_t)ncol * p.ldb : p.B + ncol;
+
+  f32x4 ra[PD][TM];
+  f32x4 rb[PD];
+  auto load = [&](auto s_c, int g) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_c)::value;
+    const int k = 16 * g + 4 * q;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) ra[s][tm] = load4(arow[tm] + k, p.K - k, p.avec);
+    if constexpr (TB) {
+      rb[s] = load4(bptr + k, p.K - k, p.bvec);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) rb[s][jj] = (k + jj < p.K) ? bptr[(size_t)(k + jj) * p.ldb] : 0.f;
+    }
+  };
+  f32x4 acc[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) acc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](auto s_c) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_c)::value;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[s][tm][jj], rb[s][jj], acc[tm], 0, 0, 0);
+  };
+  auto step = [&](auto s_c, int g) __attribute__((always_inline)) {
+    if (g < g1) {
+      compute(s_c);
+      if (g + PD < g1) load(s_c, g + PD);
+    }
+  };
+  if (g0 < g1) load(std::integral_constant<int, 0>{}, g0);
+  if (g0 + 1 < g1) load(std::integral_constant<int, 1>{}, g0 + 1);
+  if constexpr (PD == 4) {
+    if (g0 + 2 < g1) load(std::integral_constant<int, 2>{}, g0 + 2);
+    if (g0 + 3 < g1) load(std::integral_constant<int, 3>{}, g0 + 3);
+  }
+  for (int g = g0; g < g1; g += PD) {
+    step(std::integral_constant<int, 0>{}, g);
+    step(std::integral_constant<int, 1>{}, g + 1);
+    if constexpr (PD == 4) {
+      step(std::integral_constant<int, 2>{}, g + 2);
+      step(std::integral_constant<int, 3>{}, g + 3);
+    }
+  }
+  // ---- the waves' partial tiles through LDS, summed in wave order ----
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * TM + tm) * 256 + r * 64 + lane] = acc[tm][r];
+  __syncthreads();
+  for (int o = tid; o < TM * 256; o += 64 * WK_WAVES) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WK_WAVES; ++w) v += red[w * TM * 256 + o];
+    const int tm = o >> 8, r = (o >> 6) & 3, l = o & 63;
+    const int m = m0 + tm * 16 + (l >> 4) * 4 + r, n = n0 + (l & 15);
+    if (m < p.M && n < p.N) {
+      float* c = p.C + (size_t)m * p.ldc + n;
+      if (p.bias) v += p.bias[n];
+      if (p.accumulate) v += *c;
+      *c = v;
+    }
+  }
+}
+
+// rows per tile = 16 TM: the largest TM of {6, 4, 2, 1} that still gives >= 224 workgroups (one per CU with some slack), else 1
+static int gemm_wk_tm(int M, int N) {
+  const int ntn = sgg_cdiv(N, 16);
+  const int cand[4] = {6, 4, 2, 1};
+  for (int c = 0; c < 4; ++c)
+    if (cand[c] * 16 <= ((M + 15) / 16) * 16 && sgg_cdiv(M, 16 * cand[c]) * ntn >= 224) return cand[c];
+  return 1;
+}
+template <bool TB>
+static void gemm_wk_launch(const GemmParams& p, hipStream_t st) {
+  const int tm = gemm_wk_tm(p.M, p.N);
+  const dim3 grid(sgg_cdiv(p.M, 16 * tm) * sgg_cdiv(p.N, 16));
+  if (tm == 6) hipLaunchKernelGGL((gemm_wk_kernel<6, TB, 2>), grid, dim3(64 * WK_WAVES), 0, st, p);
+  else if (tm == 4) hipLaunchKernelGGL((gemm_wk_kernel<4, TB, 2>), grid, dim3(64 * WK_WAVES), 0, st, p);
+  else if (tm == 2) hipLaunchKernelGGL((gemm_wk_kernel<2, TB, 4>), grid, dim3(64 * WK_WAVES), 0, st, p);
+  else hipLaunchKernelGGL((gemm_wk_kernel<1, TB, 4>), grid, dim3(64 * WK_WAVES), 0, st, p);
+}
+// the shapes that take it: NN / NT whose 64 x 64 tiling would split K over workgroups, M and K of the heads' size
+static bool gemm_wk_applicable(int mode, int M, int N, int K, int nsplit_old) {
+  return SGG_GEMM_WK && mode != 2 && nsplit_old > 1 && M <= 512 && K <= 8192 && N >= 16;
+}
+
 // smallest K range one workgroup of a split-K head GEMM takes.  These GEMMs are chains of dependent 32-deep slabs (f32 MFMA: 0.43 us
 // per slab per wave) on a handful of tiles: deeper splits shorten the chain (measured 256 -> 64: 53.16 -> 52.82 ms per G+D step)
 #ifndef SGG_GEMM_MIN_KCHUNK
@@ -210,6 +336,13 @@ static int gemm_run(int mode, int M, int N, int K, const float* A, int lda, cons
   p.avec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
   p.bvec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
   gemm_plan(M, N, K, &p.nsplit, &p.kchunk);
+  hipStream_t st = (hipStream_t)stream;
+  if (gemm_wk_applicable(mode, M, N, K, p.nsplit)) {
+    if (mode == 0) gemm_wk_launch<false>(p, st);
+    else gemm_wk_launch<true>(p, st);
+    SGG_LAUNCH_CHECK(name);
+    return SGG_OK;
+  }
   if (p.nsplit > 1) {
     const size_t need = (size_t)p.nsplit * M * N * sizeof(float);
     if (!workspace || workspace_bytes < need) {
@@ -217,7 +350,6 @@ static int gemm_run(int mode, int M, int N, int K, const float* A, int lda, cons
       return SGG_ERR_WORKSPACE;
     }
   }
-  hipStream_t st = (hipStream_t)stream;
   dim3 grid(sgg_cdiv(M, 64) * sgg_cdiv(N, 64), 1, p.nsplit);
   if (mode == 0) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, p);
   else if (mode == 1) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, p);

@@ -360,8 +360,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
 // 16-workgroup kernels of 20 us each on the critical path of the backward.
 #define SGG_LNF_MAX 16
 struct LnfLayer {
-  const float* ws;         // [B][G][2] sums (sspart, or the one-pass kernel's sstot with G = 1) as sgg_layernorm_hwc_elu_bwd left
-                           // them in the layer's workspace; the [B][G][3][C] channel sums follow
+  const float* ws;         // [B][G][2] sums (sspart) as sgg_layernorm_hwc_elu_bwd left them in the layer's workspace; the
+                           // [B][G][3][C] channel sums follow
   const float* gamma;
   const float* stats;
   float* dgamma;
@@ -436,291 +436,11 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
   if (amax_out) block_publish_amax(amax_out, amax, red);
 }
 
-// ---- backward, one pass over HBM -------------------------------------------------------------------------------
-// ln_bwd_partial + ln_bwd_apply read y and da TWICE (5 passes over the sample: 2 + 2 reads, 1 write), because dy needs two sums
-// over the whole sample.  Here a 512-thread workgroup keeps its 16384 elements of y and da IN REGISTERS (as xhat and dxhat: 64 VGPRs
-// per thread) across the reduction: it publishes its partial sums, waits until the other workgroups of its sample have published
-// theirs, and writes dy from the registers - 3 passes (y, da, dy), the floor for this operator.
-//   * PERSISTENT workgroups (as many as the device holds at once: two per CU) take (sample, piece) items by TICKET, sample-major.
-//     A workgroup only ever waits for items of its own sample, and tickets are taken in order: if every running workgroup were
-//     waiting, they would all hold items of the oldest incomplete sample - at most G - 1 of them -, so with more than G workgroups
-//     running somebody is always free to take the next ticket.  ln_bwd_plan admits the path for G <= LNB_MAXG = 128 against 512
-//     resident workgroups (118 VGPRs, 24 KB LDS), which also leaves room for launches on other streams.
-//     (One workgroup per item, handed out by the hardware dispatcher, is NOT safe: workgroup ids are bound to XCDs round robin, and
-//      when one XCD falls behind - seen in the training step, never in isolation - its 64 slots fill with workgroups waiting for
-//      tickets that only ITS not yet dispatched workgroups can take: the bounded wait expired about once per step.)
-//   * The wait is bounded (LNB_SPIN_MAX polls, about half a second): a workgroup that gives up sets the error word behind the
-//     counters and carries on with whatever sums it finds, so the grid always drains; sgg_layernorm_hwc_elu_bwd_status reads it.
-//   * The exchanged words (partial sums, arrival counters) are written and read with agent-scope atomics (sc1: the eight XCD L2s
-//     are not coherent with each other inside a kernel); the bulk data is never exchanged.  The ticket, every sample's arrival
-//     counter and the error word live in 128-byte lines of their own: pollers of one sample do not delay anybody else's atomics.
-//   * Summation orders are fixed (partials by index, wave / workgroup trees): results do not depend on arrival order.
-// MEASURED (profiles/r03_ln_bwd_one_pass.log): correct (2e-7 of an fp64 evaluation, no expired wait in 130 calls of the training
-// step), and exactly as fast as the two kernels it replaces - 374 us against 374 us on 64 x 112 x 112 x 128, 47.66 against 47.65 ms
-// per step: 3 passes at 3.3 TB/s against 5 passes at 5.5 TB/s.  The register file bounds the bytes in flight (512 workgroups x 128 KB
-// = 64 MB, 12 us of HBM bandwidth), and the exchange (write-through store, counter atomic, poll, 2 G sc1 loads: about 12 us of
-// dependent latency) sits between a workgroup's reads and its writes; the persistent workgroups fall into lock step, so the device
-// alternates read bursts, exchange latency and write bursts instead of overlapping them.  An exchange without the counter (every
-// thread polls one 8-byte slot against a sentinel) was slower still (527 us).  Hence SGG_LN_BWD_FUSED = 0 by default: the code
-// stays as the measured starting point for a form that holds a second item in LDS.
-#define LNB_T 512
-#define LNB_R 8
-#define LNB_E (LNB_T * 4 * LNB_R)
-#define LNB_MAXG 128
-#define LNB_LINE 32                 // ints per counter line
-#define LNB_LINES(B) (2 * (B) + 2)  // ticket, error word, first arrivals [B], second arrivals [B]
-#define LNB_SPIN_MAX (1 << 19)
-#ifndef SGG_LN_BWD_FUSED
-#define SGG_LN_BWD_FUSED 0      // measured equal to the two-pass kernels (see above): off; -DSGG_LN_BWD_FUSED=1 builds it in
-#endif
-
-__device__ __forceinline__ void lnb_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float lnb_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float block_sum_512(float v, float* red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-}
-
-__global__ void lnb_zero_kernel(int* p, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = 0;
-}
-// ctr: line 0 = ticket, line 1 = error word, line 2 + b = arrivals of sample b (sums published), line 2 + B + b = its second arrivals
-// (channel sums published)
-template <bool MASK>
-__global__ __launch_bounds__(LNB_T, 4) void ln_bwd_fused_kernel(const float* __restrict__ y, const float* __restrict__ da,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ stats, float* sspart, float* chpart,
-                                                                int* ctr, float* __restrict__ sstot, float* __restrict__ chsum,
-                                                                float* __restrict__ dy, long long N, int C, int G, int B,
-                                                                float* __restrict__ amax_out, LnMask mk, float nvalid) {
-  __shared__ float red[8];
-  __shared__ float chs[LNB_T * 12];
-  __shared__ int tk, last_s;
-  const int items = G * B;
-  const int logC = 31 - __builtin_clz(C);      // (C is a power of two)
-  float amax = 0.f;
-  if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (;;) {
-  __syncthreads();
-  const int ticket = __builtin_amdgcn_readfirstlane(tk);      // (uniform: sample pointers and statistics in SGPRs)
-  if (ticket >= items) break;
-  const int b = ticket / G, g = ticket - b * G;
-  // Everything derived from the thread index is re-derived per item from an opaque copy: hoisted out of the item loop these values
-  // (addresses, LDS indices) cost twenty VGPRs that the 128-register budget of two workgroups per CU does not have
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int ch = (tid * 4) & (C - 1);      // constant across j: 4 * LNB_T is a multiple of C (C <= 1024)
-  const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
-  const float* yb = y + (size_t)b * N;
-  const float* db = da + (size_t)b * N;
-  float* ob = dy + (size_t)b * N;
-  const int base = g * LNB_E + tid * 4;      // element of the sample (< 2^21: G <= LNB_MAXG): 32-bit offsets from uniform bases
-  // (per item, not per workgroup: eight registers that need not live across the wait)
-  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + ch);
-  const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + ch);
-  // ---- phase 1: load, reduce; v <- xhat, d <- dxhat (branch free: lanes outside the sample / the valid window read element 0 of
-  // the sample and contribute zeros) ----
-  f32x4 v[LNB_R], d[LNB_R];
-  int in_n = 0, okm = 0;
-#pragma unroll
-  for (int j = 0; j < LNB_R; ++j) {
-    const int e = base + 4 * LNB_T * j;
-    const bool inside = e < N;
-    const bool ok = inside && (!MASK || ln_valid(mk, e));
-    in_n |= (int)inside << j;
-    okm |= (int)ok << j;
-    const int el = ok ? e : 0;
-    v[j] = ln_ld(yb + el);
-    d[j] = ln_ld(db + el);
-  }
-  f32x4 sA = {0.f, 0.f, 0.f, 0.f}, sB = sA, sX = sA;
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int j = 0; j < LNB_R; ++j) {
-    const float keep = (okm >> j) & 1 ? 1.f : 0.f;
-    const f32x4 xh = (v[j] - mean) * (rstd * keep);
-    const f32x4 n = xh * gm + bt;
-    f32x4 dn;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dn[q] = (d[j][q] * keep) * (n[q] > 0.f ? 1.f : __expf(n[q]));
-    const f32x4 dxh = dn * gm;
-    sA += dn; sB += dn * xh; sX += xh;
-    s1 += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
-    const f32x4 t = dxh * xh;
-    s2 += (t[0] + t[1]) + (t[2] + t[3]);
-    v[j] = xh;
-    d[j] = dxh;
-  }
-  const float S1 = block_sum_512(s1, red);
-  const float S2 = block_sum_512(s2, red);
-  // ---- arrive: the two sums are written through (sc1, vmcnt(0)) before the arrival is counted; wait for the sample ----
-  if (tid == 0) {
-    lnb_store(sspart + ((size_t)b * G + g) * 2 + 0, S1);
-    lnb_store(sspart + ((size_t)b * G + g) * 2 + 1, S2);
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    int* cnt = ctr + (2 + b) * LNB_LINE;
-    int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    int polls = 0;
-    while (seen < G && polls < LNB_SPIN_MAX) {
-      __builtin_amdgcn_s_sleep(16);
-      seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ++polls;
-    }
-    if (seen < G) {
-      __hip_atomic_store(ctr + LNB_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef SGG_LNB_DEBUG      // scripts/debug_lnb.py: who gave up first, and what it saw (the words behind the flag in the error line)
-      if (__hip_atomic_fetch_add(ctr + LNB_LINE + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        ctr[LNB_LINE + 2] = b; ctr[LNB_LINE + 3] = seen; ctr[LNB_LINE + 4] = ticket; ctr[LNB_LINE + 5] = G;
-        ctr[LNB_LINE + 6] = __hip_atomic_fetch_add(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ctr[LNB_LINE + 7] = __hip_atomic_fetch_add(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#endif
-    }
-  }
-  __syncthreads();
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  float a1 = 0.f, a2 = 0.f;
-  for (int i = tid; i < G; i += LNB_T) {
-    a1 += lnb_load(sspart + ((size_t)b * G + i) * 2 + 0);
-    a2 += lnb_load(sspart + ((size_t)b * G + i) * 2 + 1);
-  }
-  // the next ticket, asked for now (the sample is complete: nothing below waits for anybody), used at the top of the loop
-  int next_ticket = 0;
-  if (tid == 0) next_ticket = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- phase 2: the sample's sums (fixed order), dy from the registers ----
-  const float A1 = block_sum_512(a1, red), A2 = block_sum_512(a2, red);
-  const float m1 = A1 / (MASK ? nvalid : (float)N);
-  const float m2 = A2 / (MASK ? nvalid : (float)N);
-#pragma unroll
-  for (int j = 0; j < LNB_R; ++j) {
-    if ((in_n >> j) & 1) {
-      const int e = base + 4 * LNB_T * j;
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      if ((okm >> j) & 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          o[q] = rstd * (d[j][q] - m1 - v[j][q] * m2);
-          amax = fmaxf(amax, fabsf(o[q]));
-        }
-      }
-      ln_st(ob + e, o);
-    }
-  }
-  // ---- the per-channel sums (parameter gradients), off the path the other workgroups of the sample wait on: reduce across the
-  // threads of equal channels, publish, count an arrival; the workgroup that arrives last folds the sample's G partials into one
-  // row (sstot[b], chsum[b][3][C]), so that ln_bwd_finalize reads one row per sample instead of G ----
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    chs[tid * 12 + q] = sA[q];
-    chs[tid * 12 + 4 + q] = sB[q];
-    chs[tid * 12 + 8 + q] = sX[q];
-  }
-  __syncthreads();
-  const int nit = 3 * C;
-  {
-    const int tpc = C >> 2, reps = (LNB_T * 4) >> logC;      // thread classes (equal channels), threads per class
-    float* o = chpart + ((size_t)b * G + g) * nit;
-    for (int item = tid; item < nit; item += LNB_T) {
-      const int which = item >> logC, cc = item & (C - 1);
-      const int t0 = cc >> 2, q = cc & 3;
-      float s = 0.f;
-      for (int r = 0; r < reps; ++r) s += chs[(t0 + r * tpc) * 12 + which * 4 + q];
-      lnb_store(o + item, s);
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): every thread's words (and its dy stores) are out
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  __syncthreads();
-  if (tid == 0) {
-    last_s = __hip_atomic_fetch_add(ctr + (2 + B + b) * LNB_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
-    tk = next_ticket;
-  }
-  __syncthreads();
-  if (last_s) {      // (uniform) every partial of sample b is visible; the g range is split over 512 / (3 C) thread groups, combined in
-                     // group order: a fixed order again
-    if (tid == 0) {
-      sstot[b * 2 + 0] = A1;
-      sstot[b * 2 + 1] = A2;
-    }
-    const int ngrp = nit <= LNB_T ? LNB_T / nit : 1;
-    const int glen = (G + ngrp - 1) / ngrp;
-    const float* src = chpart + (size_t)b * G * nit;
-    float* dst = chsum + (size_t)b * nit;
-    if (ngrp > 1) {
-      const int grp = tid / nit, item = tid - grp * nit;
-      float sum = 0.f;
-      if (grp < ngrp) {
-        const int g1 = (grp + 1) * glen < G ? (grp + 1) * glen : G;
-        for (int gg = grp * glen; gg < g1; ++gg) sum += lnb_load(src + (size_t)gg * nit + item);
-      }
-      chs[tid] = sum;
-      __syncthreads();
-      if (tid < nit) {
-        float tot = 0.f;
-        for (int k = 0; k < ngrp; ++k) tot += chs[k * nit + tid];
-        dst[tid] = tot;
-      }
-    } else {
-      for (int item = tid; item < nit; item += LNB_T) {
-        float sum = 0.f;
-        for (int gg = 0; gg < G; ++gg) sum += lnb_load(src + (size_t)gg * nit + item);
-        dst[item] = sum;
-      }
-    }
-  }
-  }
-  if (amax_out) {
-    amax = wave_max(amax);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      atomic_amax(amax_out, fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]))));
-  }
-}
-
 // ---- host ----------------------------------------------------------------------------------------------
-// Backward geometry: workgroups per sample of the partial sums the backward leaves in the workspace (sspart, chpart), and whether
-// the one-pass kernel produces them (both entry points that touch the workspace ask here, so they agree)
-struct LnBwdPlan {
-  int fused;
-  int G;
-};
-static LnBwdPlan ln_bwd_plan(int B, int HW, int C) {
-  const LnGeom g = ln_geom(B, HW, C);
-  const long long gf = (g.N + LNB_E - 1) / LNB_E;
-  if (SGG_LN_BWD_FUSED && gf <= LNB_MAXG) return LnBwdPlan{1, (int)gf};
-  return LnBwdPlan{0, g.G};
-}
-// workgroups of the one-pass kernel the current device holds at once (occupancy x CUs), asked once per instantiation
-template <bool MASK>
-static int ln_bwd_resident_wgs() {
-  static int n = 0;
-  if (n == 0) {
-    int per_cu = 0, cus = 0, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_bwd_fused_kernel<MASK>, LNB_T, 0) == hipSuccess)
-      n = per_cu * cus;
-    if (n <= 0) n = -1;
-  }
-  return n;
-}
-// counter lines of the one-pass kernel: behind chpart, on a 128-byte boundary (the workspace size has the slack)
-static int* ln_bwd_counters(float* chpart, int B, int G, int C) {
-  const uintptr_t end = reinterpret_cast<uintptr_t>(chpart + (size_t)B * G * 3 * C);
-  return reinterpret_cast<int*>((end + 127) & ~(uintptr_t)127);
-}
 extern "C" size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C) {
   const LnGeom g = ln_geom(B, HW, C);
-  const LnBwdPlan bp = ln_bwd_plan(B, HW, C);
-  // fwd: part[B][G][SGG_TS]; bwd: sspart[B][Gb][2] + chpart[B][Gb][3][C] + counter lines (ticket, error word, arrivals[B]) and per-sample totals
-  // sstot[B][2] + chsum[B][3][C] of the one-pass kernel
-  return ((size_t)B * g.G * SGG_TS + (size_t)B * bp.G * 2 + (size_t)B * bp.G * 3 * C + (size_t)LNB_LINES(B) * LNB_LINE + (size_t)B * (2 + 3 * C)) * sizeof(float) + 256;
+  // fwd: part[B][G][SGG_TS]; bwd: sspart[B][G][2] + chpart[B][G][3][C]
+  return ((size_t)B * g.G * SGG_TS + (size_t)B * g.G * 2 + (size_t)B * g.G * 3 * C) * sizeof(float) + 256;
 }
 
 static int ln_check(const char* name, int B, int HW, int C, size_t ws_bytes, void* ws) {
@@ -803,36 +523,11 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
   float nvalid;
   if ((rc = ln_mask("sgg_layernorm_hwc_elu_bwd", HW, C, W, y0, x0, Hv, Wv, mk, nvalid))) return rc;
   const LnGeom g = ln_geom(B, HW, C);
-  const LnBwdPlan bp = ln_bwd_plan(B, HW, C);
   hipStream_t st = (hipStream_t)stream;
   float* sspart = (float*)ws + (size_t)B * g.G * SGG_TS;
-  float* chpart = sspart + (size_t)B * bp.G * 2;
+  float* chpart = sspart + (size_t)B * g.G * 2;
   const size_t sm = (size_t)(2 * B + LNF_BL * 32 * 3) * sizeof(float);
   const int hw_valid = W == 0 ? HW : Hv * Wv;
-  if (bp.fused) {
-    int* ctr = ln_bwd_counters(chpart, B, bp.G, C);
-    float* sstot = reinterpret_cast<float*>(ctr + (size_t)LNB_LINES(B) * LNB_LINE);      // [B][2], then chsum [B][3][C]
-    float* chsum = sstot + (size_t)B * 2;
-    // (a kernel, not hipMemsetAsync: a small hipMemsetAsync is one more call whose stream behaviour this path would depend on)
-    hipLaunchKernelGGL(lnb_zero_kernel, dim3(sgg_cdiv(LNB_LINES(B) * LNB_LINE, 256)), dim3(256), 0, st, ctr, LNB_LINES(B) * LNB_LINE);
-    const int cap = W == 0 ? ln_bwd_resident_wgs<false>() : ln_bwd_resident_wgs<true>();
-    if (cap <= bp.G) {
-      sgg_set_error("sgg_layernorm_hwc_elu_bwd: the device holds %d workgroups of the one-pass kernel, %d needed", cap, bp.G + 1);
-      return SGG_ERR_LAUNCH;
-    }
-    const int wgs = cap < bp.G * B ? cap : bp.G * B;
-    if (W == 0)
-      hipLaunchKernelGGL(ln_bwd_fused_kernel<false>, dim3(wgs), dim3(LNB_T), 0, st, y, da, gamma, beta, stats, sspart, chpart, ctr,
-                         sstot, chsum, dy, g.N, C, bp.G, B, amax_out, mk, nvalid);
-    else
-      hipLaunchKernelGGL(ln_bwd_fused_kernel<true>, dim3(wgs), dim3(LNB_T), 0, st, y, da, gamma, beta, stats, sspart, chpart, ctr,
-                         sstot, chsum, dy, g.N, C, bp.G, B, amax_out, mk, nvalid);
-    if (dgamma)      // (one row per sample: the kernel's last arrivals have folded the G partials)
-      hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sstot,
-                         (const float*)chsum, gamma, stats, dgamma, dbeta, dbias_prev, B, C, 1, hw_valid);
-    SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd");
-    return SGG_OK;
-  }
   if (W == 0)
     hipLaunchKernelGGL(ln_bwd_partial_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart,
                        g.N, C, g.G, g.cpg, mk);
@@ -849,25 +544,6 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
     hipLaunchKernelGGL(ln_bwd_apply_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats,
                        (const float*)sspart, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
   SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd");
-  return SGG_OK;
-}
-
-// 0: the last sgg_layernorm_hwc_elu_bwd on this workspace completed normally (or ran the two-pass kernels, which never wait);
-// 1: a workgroup of the one-pass kernel gave up waiting for its sample's partial sums - dy of that call is not valid.
-// Synchronises with `stream` and copies one word to the host: a debugging / test aid, not part of the training step.
-extern "C" int sgg_layernorm_hwc_elu_bwd_status(const void* ws, int B, int HW, int C, int* timed_out, void* stream) {
-  SGG_CHECK_ARG(ws && timed_out && B > 0 && HW > 0 && C >= 4, "sgg_layernorm_hwc_elu_bwd_status: bad argument");
-  *timed_out = 0;
-  const LnGeom g = ln_geom(B, HW, C);
-  const LnBwdPlan bp = ln_bwd_plan(B, HW, C);
-  if (!bp.fused) return SGG_OK;
-  float* sspart = (float*)const_cast<void*>(ws) + (size_t)B * g.G * SGG_TS;
-  const int* ctr = ln_bwd_counters(sspart + (size_t)B * bp.G * 2, B, bp.G, C);
-  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
-      hipMemcpy(timed_out, ctr + LNB_LINE, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
-    sgg_set_error("sgg_layernorm_hwc_elu_bwd_status: %s", hipGetErrorString(hipGetLastError()));
-    return SGG_ERR_LAUNCH;
-  }
   return SGG_OK;
 }
 
@@ -891,15 +567,8 @@ extern "C" int sgg_layernorm_hwc_bwd_finalize(const sgg_ln_finalize_desc* layers
                       d.HW_valid <= d.HW, "sgg_layernorm_hwc_bwd_finalize: layer %d: bad argument", i);
     const LnGeom g = ln_geom(d.B, d.HW, d.C);
     LnfLayer& L = a.L[i];
-    const LnBwdPlan bp = ln_bwd_plan(d.B, d.HW, d.C);
-    float* sspart = (float*)const_cast<void*>(d.workspace) + (size_t)d.B * g.G * SGG_TS;      // (behind the forward's partials)
-    if (bp.fused) {      // one row per sample (sstot, chsum) behind the counter lines
-      L.ws = reinterpret_cast<const float*>(ln_bwd_counters(sspart + (size_t)d.B * bp.G * 2, d.B, bp.G, d.C) + (size_t)LNB_LINES(d.B) * LNB_LINE);
-      L.G = 1;
-    } else {
-      L.ws = sspart;
-      L.G = bp.G;
-    }
+    L.ws = (const float*)d.workspace + (size_t)d.B * g.G * SGG_TS;      // (behind the forward's partials)
+    L.G = g.G;
     L.gamma = d.gamma; L.stats = d.stats; L.dgamma = d.dgamma; L.dbeta = d.dbeta; L.dbias = d.dbias_prev;
     L.B = d.B; L.C = d.C; L.HW = d.HW_valid;
     a.first[i] = tot;

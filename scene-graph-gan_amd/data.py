@@ -103,9 +103,25 @@ class ShuffledStream:
         """Elements [start, start + count) of the shuffled stream (rewinds and replays when `start` lies behind the cursor)."""
         if start < self.emitted:
             self._reset()
-        while self.emitted < start:
-            self.draw()
+        self._skip(start - self.emitted)
         return [self.draw() for _ in range(count)]
+
+    def _skip(self, count):
+        """Advance the stream by `count` draws without materialising them (a resumed run starts at iteration itr: itr * B * world
+        draws).  Same random stream as `draw` (RandomState.randint yields the same values one at a time and in blocks: pinned in
+        tests/test_data_eval.py); only the buffer state matters: a slot holds the element put there by the LAST draw that hit it."""
+        buf = np.asarray(self.buf, dtype=np.int64)
+        while count > 0:
+            m = min(count, 1 << 20)
+            js = self.rng.randint(len(self.buf), size=m)
+            last = np.full(len(self.buf), -1, dtype=np.int64)
+            last[js] = np.arange(m, dtype=np.int64)              # repeated indices: the last assignment stays
+            hit = last >= 0
+            buf[hit] = (self.next_in + last[hit]) % self.n
+            self.next_in += m
+            self.emitted += m
+            count -= m
+        self.buf = buf.tolist()
 
     def batch(self, it, batch_size, rank=0, world=1):
         """Global batch `it` is elements [it * B * world, (it + 1) * B * world) of the stream; rank r takes rows [r * B, (r + 1) * B)."""

@@ -44,7 +44,6 @@ SIGNATURES = {
     "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 9 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_vp, _sz, _vp]),
     "sgg_layernorm_hwc_bwd_finalize": (_i, [_vp, _i, _vp]),
-    "sgg_layernorm_hwc_elu_bwd_status": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "sgg_layernorm_hwc_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sgg_spatial_mean_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -129,12 +128,60 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+# Documented run-time options of HipKernels (the whole experiment surface of the host side; everything else is a build-time
+# -D switch of the library).  HipKernels(options={...}) takes any subset; scripts may override them without
+# touching code through ONE environment variable, SGG_OPTIONS="key=value,key=value" (lists: values joined by '+').
+DEFAULT_OPTIONS = {
+    # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
+    #   2 (default) f32 operands scaled by a per-tensor power of two and split into two fp16 pieces with round-to-nearest
+    #               (23 significant bits), 3 fp16 MFMAs per product, f32 accumulate: error against fp64 within 2x the native
+    #               f32 path's + 3e-7 (tests/test_fullsize_conv_gpu.py);
+    #   6           three bf16 pieces, 6 bf16 MFMAs (no scaling needed): also f32-equivalent, slower;
+    #   0           native f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 fmaf chain);
+    #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance);
+    #   1 / 4       ONE fp16 / bf16 piece: mixed-precision modes, NOT the reference's arithmetic (include/sgg_hip.h).
+    "conv_precision": 2,
+    # False: every convolution on the gather kernels (no resident halo / band / producer-consumer kernels)
+    "conv_halo": True,
+    # False: the 128-column 3x3 layers stay on the four-wave halo kernel (w_split_layout 1 instead of 4)
+    "halo_pc": True,
+    # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = per layer and per KIND of
+    # encoder pass (forward-only / followed by a backward) where trunk.ln_fusion_pays' measured cost model says it pays
+    # (trunk._plan_ln_fusion: 28 of the 44 apply passes of a step at configs[1]); 2 = wherever the kernels allow (slower:
+    # DESIGN.md); 0 = never
+    "ln_fusion": 1,
+    # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward
+    "ln_fusion_skip": (),
+    "ln_fusion_force": (),
+    "ln_fusion_force_bwd": (),
+}
+
+
+def options_from_env(base=None):
+    """DEFAULT_OPTIONS (or `base`) with the overrides of SGG_OPTIONS applied: the one environment hook of the host side."""
+    opts = dict(DEFAULT_OPTIONS if base is None else base)
+    for item in filter(None, os.environ.get("SGG_OPTIONS", "").split(",")):
+        key, _, val = item.partition("=")
+        key = key.strip()
+        if key not in DEFAULT_OPTIONS:
+            raise SggError("SGG_OPTIONS: unknown option %r (known: %s)" % (key, ", ".join(sorted(DEFAULT_OPTIONS))))
+        d = DEFAULT_OPTIONS[key]
+        if isinstance(d, bool):
+            opts[key] = val.strip().lower() not in ("0", "false", "no", "off", "")
+        elif isinstance(d, tuple):
+            opts[key] = tuple(int(v) for v in val.split("+") if v.strip())
+        else:
+            opts[key] = int(val)
+    return opts
+
+
 class HipKernels:
-    """Tensor-level wrapper of the C ABI. All tensors must be fp32 (int64 where stated) on one HIP device."""
+    """Tensor-level wrapper of the C ABI. All tensors must be fp32 (int64 where stated) on one HIP device.
+    options: a subset of DEFAULT_OPTIONS; they become attributes of the same name (read by trunk.py)."""
 
     name = "hip"
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, options=None):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise SggError("no HIP device visible: the scene-graph-gan_amd product path has no CPU fallback")
@@ -143,27 +190,14 @@ class HipKernels:
         self.timing = None      # bench.py sets this to a list: launches are then bracketed by HIP events
         self.timing_conv_only = False   # True: only the MFMA-bound convolution calls are bracketed (the timed region of bench.py)
         self.timing_symbols = None      # with timing_conv_only True: bracket only these kernel symbols (bench.py: the dominant one)
-        # Convolution contraction mode (csrc/conv_gather.hip, conv_wgrad.hip):
-        #   2 (default) f32 operands scaled by a per-tensor power of two and split into two fp16 pieces with round-to-nearest
-        #               (23 significant bits), 3 fp16 MFMAs per product, f32 accumulate: error against fp64 within 2x the native
-        #               f32 path's + 3e-7 (tests/test_fullsize_conv_gpu.py);
-        #   6           three bf16 pieces, 6 bf16 MFMAs (no scaling needed): also f32-equivalent, slower;
-        #   0           native f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 fmaf chain);
-        #   3           two bf16 pieces, 3 MFMAs: drops 2^-17 cross terms (inside the stated 1e-4 tolerance).
-        self.conv_precision = int(os.environ.get("SGG_CONV_PRECISION", "2"))
-        self.conv_halo = os.environ.get("SGG_CONV_HALO", "1") != "0"
-        # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = per layer and per KIND of
-        # encoder pass (forward-only / followed by a backward) where trunk.ln_fusion_pays' measured cost model says it pays
-        # (trunk._plan_ln_fusion: 28 of the 44 apply passes of a step at configs[1]); 2 = wherever the kernels allow (slower:
-        # DESIGN.md); 0 = never
-        self.ln_fusion = int(os.environ.get("SGG_LN_FUSION", "1"))
-        # A/B switch: 1 = layers whose forward applies an LN prologue also run the producer / consumer kernel (trunk._query_layouts)
-        self.halo_pc_ln_prologue = os.environ.get("SGG_HALO_PC_LNP", "0") == "1"
-        self.ln_fusion_skip = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_SKIP", "").split(",") if v)   # A/B: conv indices
-        self.ln_fusion_force = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_FORCE", "").split(",") if v)  # A/B: forward-only passes
-        self.ln_fusion_force_bwd = tuple(int(v) for v in os.environ.get("SGG_LN_FUSION_FORCE_BWD", "").split(",") if v)  # A/B: passes with backward
-        # A/B switch: 0 = re-derive the weight operand formats layer by layer (~45 launches per encoder) instead of prepare_weights
-        self.fused_weight_prep = os.environ.get("SGG_WEIGHT_PREP", "1") != "0"
+        opts = options_from_env()
+        for key, val in (options or {}).items():
+            if key not in DEFAULT_OPTIONS:
+                raise SggError("HipKernels: unknown option %r" % key)
+            opts[key] = val
+        for key, val in opts.items():
+            setattr(self, key, tuple(val) if isinstance(DEFAULT_OPTIONS[key], tuple) else val)
+        self.conv_precision = int(self.conv_precision)
         assert self.conv_precision in (0, 1, 2, 3, 4, 6)       # 1 / 4: single-piece (mixed-precision) modes, include/sgg_hip.h
         self._amax_by_stream = {}
 
@@ -264,7 +298,8 @@ class HipKernels:
         (128-column tiles); SGG_CONV_HALO=0 keeps every layer on the gather kernel."""
         if not self.conv_halo:
             return 0
-        return self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
+        lay = self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
+        return 1 if (lay == 4 and not self.halo_pc) else lay
 
     def split_weights(self, w, out, amax=None, layout=0):
         """w fp32 [kh, kw, N, C] -> out int16 [P, n] sixteen-bit planes (layout 0) or MFMA B fragments (layout 1)."""
@@ -350,11 +385,14 @@ class HipKernels:
                                                              self.halo_symbol(d[6], 4 * d[3], ln is not None) if w_split_layout == 3 else
                                                              self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None, ln is not None) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
+        nb = 0.0
         if d[3] != 3:
             amax_x, amax_w = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(w_fwd, amax_w, 1)
+        else:
+            nb = 4.0 * (x.numel() + y.numel())      # conv1_1 (K = 27) is HBM-bound: the image read once, y written once
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
             _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, w_split_layout, _p(amax_x), _p(amax_w),
-            _p(tile_stats), _p(ln_s), _p(ln_g), _p(ln_b), self._stream())), "sgg_conv2d_nhwc_fwd")
+            _p(tile_stats), _p(ln_s), _p(ln_g), _p(ln_b), self._stream()), nb), "sgg_conv2d_nhwc_fwd")
 
     def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None, w_split_layout=0):
         self._dev(dy, w_hwio, dx)
@@ -379,11 +417,14 @@ class HipKernels:
         need = self.lib.sgg_conv2d_nhwc_wgrad_workspace_bytes(*d[:9])
         ws = self.workspace(need)
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
+        sym, nb = "conv_wgrad(call: wgrad kernel + slab reduce)", 0.0
         if d[3] != 3:
             amax_x, amax_dy = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(dy, amax_dy, 1)
-        self._check(self._timed("conv_wgrad(call: wgrad kernel + slab reduce)", flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
+        else:
+            sym, nb = "conv_c3_wgrad(call: kernel + slab reduce)", 4.0 * (x.numel() + dy.numel())      # conv1_1: HBM-bound
+        self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
             _p(x), _p(dy), _p(dw), *d, self.conv_precision, 0 if self.conv_halo else 1, _p(amax_x), _p(amax_dy), _p(ln_s), _p(ln_g), _p(ln_b),
-            _p(ws), ws.numel(), self._stream())),
+            _p(ws), ws.numel(), self._stream()), nb),
             "sgg_conv2d_nhwc_wgrad")
 
     @staticmethod
@@ -457,17 +498,6 @@ class HipKernels:
         self._check(self.lib.sgg_layernorm_hwc_bwd_finalize(ctypes.addressof(descs), len(descs), self._stream()),
                     "sgg_layernorm_hwc_bwd_finalize")
 
-    def ln_bwd_timed_out(self, shape, ws=None):
-        """True if the last ln_elu_bwd on this workspace (default: the shared one) gave up its bounded wait for a sample's partial
-        sums (sgg_layernorm_hwc_elu_bwd_status; synchronises)."""
-        B, H, W, C = shape
-        if ws is None:
-            ws = self.workspace(self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C))
-        flag = ctypes.c_int(0)
-        self._check(self.lib.sgg_layernorm_hwc_elu_bwd_status(_p(ws), B, H * W, C, ctypes.addressof(flag), self._stream()),
-                    "sgg_layernorm_hwc_elu_bwd_status")
-        return bool(flag.value)
-
     def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None, ws=None):
         """dgamma = dbeta = None with a workspace `ws` of the layer's own: the parameter-gradient reductions are deferred to
         ln_bwd_finalize."""
@@ -478,8 +508,7 @@ class HipKernels:
         if ws is None:
             ws = self.workspace(need)
         assert ws.numel() * ws.element_size() >= need
-        # bytes of the two-pass form (the reduction reads y and da, the apply pass reads them again and writes dy); the one-pass
-        # kernel moves 3/5 of them
+        # bytes: the reduction reads y and da, the apply pass reads them again and writes dy
         self._check(self._timed("ln_elu_bwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_bwd(
             _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma), _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C,
             *self._region(region, H, W), _p(ws), ws.numel() * ws.element_size(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")

@@ -121,6 +121,9 @@ class ParamArena:
         self.device, self.dtype = torch.device(device), dtype
         self.flat = torch.zeros(self.total_numel, dtype=dtype, device=self.device)
         self.views = self._make_views(self.flat)
+        # bumped whenever the parameters change (optimiser step, load_state_dict): encoders derive operand formats from the weights
+        # (trunk.refresh_weights) and several of them - one per batch size - may share this arena
+        self.version = 0
 
     def _make_views(self, flat):
         v = OrderedDict()
@@ -149,6 +152,7 @@ class ParamArena:
             if tuple(src.shape) != tuple(self.shapes[n]):
                 raise ValueError("shape mismatch for %s: %s vs %s" % (n, tuple(src.shape), self.shapes[n]))
             self.views[n].copy_(src.to(self.dtype))
+        self.version += 1
 
     def state_dict(self, full_names=False):
         return OrderedDict(((tf_variable_name(self.kind, n) if full_names else n), v.detach().clone().cpu())

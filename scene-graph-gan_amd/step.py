@@ -31,21 +31,34 @@ def tf_adam_lr_t(t, lr=ADAM_LR, b1=ADAM_B1, b2=ADAM_B2):
 
 
 class Network:
-    """Parameters (+ gradient / Adam arenas), encoder and head of one network."""
+    """Parameters (+ gradient / Adam arenas), encoder and head of one network for ONE batch size.
 
-    def __init__(self, K, kind, V, S, B, E=EMBED_DIM, device=None, dtype=torch.float32, state_dict=None):
+    share=<Network>: the variables of the reference graph exist once however many times build_* runs (tf.AUTO_REUSE, train.py:86,91;
+    the graph is batch-dynamic: generator_with_attention.py:74-75 reshape to [-1, ...], train.py:29-30,199-203,297-298 feed B, B/2
+    and B/2 x 8 rows through the same ops).  A Network built with `share` uses the other one's parameter, gradient and Adam arenas
+    and optimiser step count, and owns only the activation buffers of its own batch size."""
+
+    def __init__(self, K, kind, V, S, B, E=EMBED_DIM, device=None, dtype=torch.float32, state_dict=None, share=None):
         self.K, self.kind = K, kind
         device = device if device is not None else K.device
-        self.arena = ParamArena(kind, V, S, E, device=device, dtype=dtype)
-        if state_dict is not None:
-            self.arena.load_state_dict(state_dict)
-        self.grad_flat, self.grads = self.arena.like()
-        self.m_flat, _ = self.arena.like()
-        self.v_flat, _ = self.arena.like()
-        self.adam_t = 0
-        self.pending = None          # in-flight gradient all-reduce (dp.PendingReduce) whose Adam step is deferred
+        if share is not None:
+            assert state_dict is None and (share.kind, share.arena.V, share.arena.S, share.arena.E) == (kind, V, S, E)
+            self.arena, self.grad_flat, self.grads = share.arena, share.grad_flat, share.grads
+            self.m_flat, self.v_flat, self.opt = share.m_flat, share.v_flat, share.opt
+        else:
+            self.arena = ParamArena(kind, V, S, E, device=device, dtype=dtype)
+            if state_dict is not None:
+                self.arena.load_state_dict(state_dict)
+            self.grad_flat, self.grads = self.arena.like()
+            self.m_flat, _ = self.arena.like()
+            self.v_flat, _ = self.arena.like()
+            # t: Adam step count; pending: in-flight gradient all-reduce (dp.PendingReduce) whose Adam step is deferred
+            self.opt = {"t": 0, "pending": None}
         self.trunk = Trunk(K, self.arena, self.grads, B, S)
         self.head = Head(K, kind, self.arena, self.grads, B, self.trunk.L)
+
+    adam_t = property(lambda self: self.opt["t"], lambda self, v: self.opt.__setitem__("t", v))
+    pending = property(lambda self: self.opt["pending"], lambda self, v: self.opt.__setitem__("pending", v))
 
     def zero_grads(self):
         assert self.pending is None
@@ -70,6 +83,7 @@ class Network:
         a = self.arena
         self.K.adam(a.live(), a.live(self.grad_flat), a.live(self.m_flat), a.live(self.v_flat),
                     tf_adam_lr_t(self.adam_t), ADAM_B1, ADAM_B2, ADAM_EPS, grad_scale)
+        a.version += 1                       # (encoders of other batch sizes on this arena re-derive their operand formats lazily)
         self.trunk.refresh_weights()
 
 

@@ -71,6 +71,7 @@ def ln_fusion_pays(out_shape, cout_next):
 class Trunk:
     def __init__(self, K, arena, grad_views, B, S):
         self.K, self.B, self.S = K, B, S
+        self.arena = arena
         dev, dt = arena.flat.device, arena.flat.dtype
         p, g = arena.views, grad_views
         self.layers = []
@@ -158,7 +159,7 @@ class Trunk:
         if lay["cin"] != 3 and hasattr(K, "conv_wsplit_layout"):
             k, s = lay["k"], lay["s"]
             lay["ws_layout"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cin"], lay["cout"])
-            if lay["ws_layout"] == 4 and not getattr(K, "halo_pc_ln_prologue", False) and self._ln_prologue_expected(lay):
+            if lay["ws_layout"] == 4 and self._ln_prologue_expected(lay):
                 # The producer / consumer 3x3 kernel (layout 4) wins without the LayerNorm prologue (408-413 against 384 TFLOP/s in the
                 # step) and loses with it (337-345 against 358: its four producer waves carry all of the prologue's v_exp work beside one
                 # MFMA wave per SIMD).  A layer whose forward mostly runs with the prologue keeps the four-wave kernel's fragments for
@@ -211,9 +212,9 @@ class Trunk:
                 lay["fuse_ln"] = lay["fuse_ln_bwd"] = both_ok
                 continue
             pays_fwd, pays_bwd = ln_fusion_pays(lay["out_shape"], nxt["cout"])
-            if lay["i"] in getattr(K, "ln_fusion_skip", ()):      # (A/B switch SGG_LN_FUSION_SKIP of sgg_amd/lib.py)
+            if lay["i"] in getattr(K, "ln_fusion_skip", ()):      # (A/B option ln_fusion_skip of sgg_amd/lib.py)
                 pays_fwd = pays_bwd = False
-            if lay["i"] in getattr(K, "ln_fusion_force", ()):     # (A/B switch SGG_LN_FUSION_FORCE)
+            if lay["i"] in getattr(K, "ln_fusion_force", ()):     # (A/B option ln_fusion_force)
                 pays_fwd = True
             if lay["i"] in getattr(K, "ln_fusion_force_bwd", ()):
                 pays_bwd = True
@@ -225,7 +226,8 @@ class Trunk:
         HWOI transposes, max|w| words, the space-to-depth kernel of conv1_3, both pre-split 16-bit copies.  One multi-tensor call
         (three launches for the whole encoder) where the kernel set has it; per layer otherwise (the CPU reference kernels)."""
         K = self.K
-        if hasattr(K, "prepare_weights") and getattr(K, "fused_weight_prep", True):
+        self._wver = getattr(self.arena, "version", 0)
+        if hasattr(K, "prepare_weights"):
             key = (K.conv_precision, getattr(K, "conv_halo", True))
             if getattr(self, "_wdesc_key", None) != key:       # layouts depend on the precision in force: rebuild the table
                 todo = []
@@ -274,6 +276,8 @@ class Trunk:
         layer may be applied by the consuming convolution's patch staging instead of a pass of its own (K.ln_fusion = 1)."""
         assert tuple(images.shape) == (self.B, self.S, self.S, 3), images.shape
         K = self.K
+        if self._wver != getattr(self.arena, "version", 0):
+            self.refresh_weights()          # the parameters changed through another encoder on this arena (another batch size)
         fuse_key = "fuse_ln_bwd" if for_backward else "fuse_ln"
         self._fwd_for_backward = for_backward
         if self.img_canvas is not None:

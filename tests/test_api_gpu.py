@@ -51,6 +51,54 @@ def test_generator_discriminator_classes_match_oracle():
         Generator(V).build_generator(images, True)          # CPU tensor: no fallback
 
 
+def test_model_objects_are_batch_dynamic_on_one_set_of_weights():
+    """The reference graph is batch-dynamic (generator_with_attention.py:74-75: reshape(..., [-1, ...])) and train.py feeds it B,
+    B / 2 (validation, :29-30, 199-203) and B / 2 x 8 (test, :297-298) rows through the same variables.  One Generator / Discriminator:
+    B = 8 and B = 4 against the oracle (logits 1e-4, tokens exact); then a critic + generator update at B = 8 (Adam on the shared
+    arenas) must be what the B = 4 build sees - again against the oracle with the UPDATED weights."""
+    from architectures.generator_with_attention import Generator
+    from architectures.discriminator_with_attention import Discriminator
+    from sgg_amd.step import GanStep
+    S, V = 64, 50
+    gp, dp = O.init_params("G", V, S), O.init_params("D", V, S)
+    g, d = Generator(V), Discriminator(V, dp["W"].clone())
+    toks = torch.empty((8, 3), dtype=torch.int64, device="cuda")
+
+    def check(B, gp, dp, what):
+        images, labels, onehot = O.synth_batch(B, S, V)
+        noise = O.synth_noise(B, 3)
+        logits = g.build_generator(images.cuda(), True, noise=noise.cuda())
+        ref = O.generator_forward(gp, images, noise)
+        close(logits, ref, "%s: Generator at B = %d" % (what, B))
+        assert O.top2_margin(ref) > 2e-5, "near-tie in the oracle's own logits: pick another seed"
+        g.net.K.argmax_rows(logits, toks[:B].view(-1))
+        assert torch.equal(toks[:B].cpu(), O.argmax_tokens(ref)), "%s: tokens at B = %d" % (what, B)
+        assert tuple(g.downsampled.shape) == (B, 4, 4, 512) and tuple(g.alpha.shape) == (B, 16)
+        out = d.build_discriminator(ref.cuda(), images.cuda())
+        close(out, O.discriminator_forward(dp, ref, images), "%s: Discriminator at B = %d" % (what, B))
+        out = d.build_discriminator(onehot.cuda(), images.cuda())
+        close(out, O.discriminator_forward(dp, onehot, images), "%s: Discriminator(real) at B = %d" % (what, B))
+        return images, labels
+
+    images8, labels8 = check(8, gp, dp, "initial weights")
+    check(4, gp, dp, "initial weights")
+    check(8, gp, dp, "initial weights, back at 8")          # the buffers of the first batch size are intact
+    assert set(g._nets) == {8, 4} and g._nets[4].arena is g.net.arena and g._nets[4].grad_flat is g.net.grad_flat
+    assert d._nets[4].m_flat is d.net.m_flat and d.embedding_matrix.data_ptr() == d.net.arena.views["W"].data_ptr()
+    # one critic update and one generator update at B = 8 on the very same objects
+    gs = GanStep(g.net.K, V, S, 8, lam=10.0, G=g._ensure(images8.cuda()), D=d._ensure(images8.cuda()))
+    gs.critic_step(images8.cuda(), labels8.cuda(), O.synth_noise(8, 0).cuda(), O.synth_alpha(8, 0).reshape(8).cuda())
+    gs.generator_step(images8.cuda(), O.synth_noise(8, 1).cuda())
+    gs.flush()
+    assert g.net.adam_t == 1 and d.net.adam_t == 1 and g._nets[4].adam_t == 1
+    gp2, dp2 = g.state_dict(full_names=False), d.state_dict(full_names=False)
+    assert float((gp2["conv2d/kernel"] - gp["conv2d/kernel"]).abs().max()) > 0 and float((dp2["W"] - dp["W"]).abs().max()) > 0
+    check(4, gp2, dp2, "after the update at B = 8")          # the B = 4 encoder re-derives its operand formats from the new weights
+    check(8, gp2, dp2, "after the update at B = 8")
+    with pytest.raises(ValueError):
+        g.build_generator(torch.zeros((2, 96, 96, 3), device="cuda"))       # the spatial size is static, as in the reference (:15)
+
+
 def test_train_entry_point_synthetic(tmp_path):
     import train as T
     gan = T.SceneGraphGAN(str(tmp_path / "ck"), str(tmp_path / "logs"), None, None, None, None, None,

@@ -52,10 +52,19 @@ def test_roofline_records_from_event_timings():
     assert abs(hbm[0]["GBps"] - 967e6 / 0.16e-3 / 1e9) < 1e-6 and abs(hbm[0]["frac_of_8TBps"] - hbm[0]["GBps"] / 8000.0) < 1e-12
 
 
+def test_exit_code_travels_in_the_json_line():
+    """torch.distributed.run collapses a rank's exit code to 1: the parent derives the parity code 3 from rank 0's line."""
+    assert bench.exit_code_from(0, json.dumps({"parity": {"ok": True}})) == 0
+    assert bench.exit_code_from(1, json.dumps({"parity": {"ok": False}})) == 3
+    assert bench.exit_code_from(0, json.dumps({"parity": {"ok": False}})) == 3
+    assert bench.exit_code_from(1, None) == 1 and bench.exit_code_from(1, "not json") == 1 and bench.exit_code_from(0, json.dumps({"value": 1})) == 0
+
+
 def test_cli_contract_flags_exist():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--config", "--critic-iters", "--cpu-rows", "--f32-steps"):
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--critic-iters", "--cpu-rows", "--f32-steps", "--serial-steps", "--single-stream",
+                 "--other-configs"):
         assert flag in out.stdout
 
 
@@ -83,3 +92,30 @@ def test_self_launch_relays_the_exit_code_of_the_ranks():
     import torch
     if not torch.cuda.is_available():
         assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_line_names_its_schedule_and_measures_the_roofline_in_serial_steps():
+    """The headline is the product's default (two-stream) schedule and says so; `roofline` comes from the serial leg, whose dominant
+    kernel's launches per step times their average duration must fit inside a serial step (a rehearsal-sized workload)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--size", "64",
+                          "--vocab", "50", "--cpu-rows", "4", "--f32-steps", "1", "--ci10-steps", "0", "--serial-steps", "2"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["config"]["schedule"] == "two-stream; per-kernel figures from serial steps"
+    assert rec["config"]["workload"].startswith("custom") and rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["serial"]["steps"] == 2 and rec["serial"]["ms_per_step"] > 0 and "other_configs" not in rec      # (not the default workload)
+    r = rec["roofline"]
+    assert r["bound"] == "mfma" and r["launches_per_step"] * r["avg_launch_ms"] <= rec["serial"]["ms_per_step"]
+    assert any(h["kernel"].startswith("conv_c3") for h in rec["roofline_hbm"]), [h["kernel"] for h in rec["roofline_hbm"]]
+    assert rec["parity"]["ok"] is True and rec["cpu_baseline"]["kind"] == "port" and rec["native_f32"]["steps"] == 1
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "4", "--size", "64",
+                          "--vocab", "50", "--cpu-rows", "0", "--f32-steps", "0", "--ci10-steps", "0", "--serial-steps", "0", "--single-stream"],
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    rec1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec1["config"]["schedule"].startswith("serial") and "roofline" not in rec1

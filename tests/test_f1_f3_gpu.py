@@ -118,10 +118,13 @@ def test_evaluation_matches_oracle(tmp_path):
     assert n_samples == 128
     g = torch.Generator().manual_seed(4242)
     imgs = [torch.randn((S, S, 3), generator=g) for _ in range(2)]
-    # the noise stream test() draws (its generator is seeded from gan.seed): one [B, 512] draw per pass, image after image
+    # the noise stream test() draws (its generator is seeded from gan.seed): TEST_BATCH_MULTIPLIER runs of TEST_BATCH_SIZE rows per
+    # image (train.py:311-318), one [TEST_BATCH_SIZE, 512] draw per run, image after image - at that batch size, on the weights
+    # trained at batch B
     gen = torch.Generator().manual_seed(gan.seed + 123)
-    passes = n_samples // B
-    noises = [[torch.randn((B, 512), generator=gen) for _ in range(passes)] for _ in imgs]
+    TB, passes = gan.TEST_BATCH_SIZE, gan.TEST_BATCH_MULTIPLIER
+    assert TB == B // 2 and passes == 8
+    noises = [[torch.randn((TB, 512), generator=gen) for _ in range(passes)] for _ in imgs]
     # true triples: taken from what the ORACLE generates (so the recalls are not trivially zero), plus never-generated ones
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     pre = [ER.evaluate_image(gp, dp, im, [[0, 0, 0]], ns) for im, ns in zip(imgs, noises)]
@@ -159,9 +162,10 @@ def test_validation_loss_early_stop_and_test_at_end(tmp_path):
     gp, dp = gan.g.state_dict(full_names=False), gan.d.state_dict(full_names=False)
     vgen = torch.Generator().manual_seed(11)
     got = gan.validation_loss(0, vgen)
-    images, labels, rep = gan._val_batch(0)
+    images, labels = gan._val_batch(0)
     VB = gan._val_rows()
-    assert VB == B // 2 and rep == 2 and tuple(images.shape) == (B, S, S, 3)
+    assert VB == B // 2 and tuple(images.shape) == (VB, S, S, 3)         # VAL_BATCH_SIZE rows through the same variables (train.py:29-30)
+    assert gan.val_step.B == VB and gan.val_step.G.arena is gan.step.G.arena and gan.val_step.D.arena is gan.step.D.arena
     g2 = torch.Generator().manual_seed(11)
     noise, alpha = torch.randn((VB, 512), generator=g2), torch.rand((VB,), generator=g2)
     onehot = torch.nn.functional.one_hot(labels[:VB].cpu(), V).float()

@@ -8,7 +8,6 @@ from sgg_amd import trunk as T
 class _K:
     conv_precision = 2
     ln_fusion = 1
-    halo_pc_ln_prologue = False
     ln_fusion_skip = ()
 
     def conv_wsplit_layout(self, k, s, H, W, cin, cout):      # what csrc/conv_gather.hip: sgg_conv_wsplit_layout answers in mode 2
@@ -58,14 +57,6 @@ def test_forward_without_prologue_takes_the_pc_kernel():
     lay = _lay(6, 128, 128, 3, 1, 112, _lay(5, 64, 128, 3, 1, 112, None))
     _trunk(K)._query_layouts(lay)
     assert lay["ws_layout"] == 4
-
-
-def test_switch_puts_every_128_column_launch_on_the_pc_kernel():
-    K = _K()
-    K.halo_pc_ln_prologue = True
-    lay = _lay(6, 128, 128, 3, 1, 112, _lay(5, 64, 128, 3, 1, 112, None))
-    _trunk(K)._query_layouts(lay)
-    assert lay["ws_layout"] == 4 and lay["ws_layout_bwd"] == 4
 
 
 def test_other_layers_are_untouched():

@@ -97,6 +97,7 @@ class SceneGraphGAN(object):
         self.g = Generator(len(self.vocab))
         self.d = Discriminator(len(self.vocab), torch.as_tensor(self.embeddings, dtype=torch.float32))
         self.step = None
+        self.val_step = None
         self.itr = 0
 
     def _createStringMappings(self):
@@ -147,10 +148,9 @@ class SceneGraphGAN(object):
         return self._stream_cache
 
     def _val_rows(self):
-        """VAL_BATCH_SIZE = BATCH_SIZE / 2 (train.py:30).  The B-row step machinery evaluates it as that batch repeated twice (every loss
-        term is a mean over rows: same value); an odd BATCH_SIZE validates on BATCH_SIZE rows instead."""
-        B = self.BATCH_SIZE
-        return B // 2 if (B % 2 == 0 and B >= 2) else B
+        """VAL_BATCH_SIZE = BATCH_SIZE / 2 (train.py:30, Python-2 integer division); the model objects take any batch size on one
+        set of weights (sgg_amd/api.py), so the validation batch runs at its own size, as in the reference graph."""
+        return max(1, self.BATCH_SIZE // 2)
 
     def _parseFunction(self, filename):
         """JPEG decode -> tf.image.resize_images([221, 221]) (TF-1.x bilinear, align_corners=False, no antialiasing) ->
@@ -181,8 +181,8 @@ class SceneGraphGAN(object):
 
     def _val_batch(self, k):
         """Validation batch k (the live validation iterator of train.py:199-203): VAL_BATCH_SIZE examples of the validation split in
-        its own repeated + shuffled order, laid out as BATCH_SIZE rows (see _val_rows)."""
-        B, VB = self.BATCH_SIZE, self._val_rows()
+        its own repeated + shuffled order."""
+        VB = self._val_rows()
         if self.dataset is None:
             g = torch.Generator().manual_seed(self.seed + 5000 + 17 * k + 1000 * self.rank)
             images = torch.randn((VB, self.image_size, self.image_size, 3), generator=g)
@@ -194,17 +194,21 @@ class SceneGraphGAN(object):
                 [(k * VB * self.world + self.rank * VB + j) % len(files) for j in range(VB)]
             images = torch.stack([self._parseFunction(files[i]) for i in idx])
             labels = torch.from_numpy(labs[idx])
-        rep = B // VB
-        return images.repeat(rep, 1, 1, 1).to(self.device), labels.repeat(rep, 1).to(self.device), rep
+        return images.to(self.device), labels.to(self.device)
 
     def validation_loss(self, k, gen):
         """np.mean(sess.run(self.disc_cost, feed_dict = {handle: val_handle})) (train.py:377): the critic's cost on validation batch k with
         fresh noise / alpha, no update; averaged over the data-parallel ranks so that every rank takes the same early-stop decision."""
-        images, labels, rep = self._val_batch(k)
+        images, labels = self._val_batch(k)
         VB = self._val_rows()
-        noise = torch.randn((VB, 512), generator=gen).repeat(rep, 1).to(self.device)
-        alpha = torch.rand((VB,), generator=gen).repeat(rep).to(self.device)
-        loss = self.step.critic_loss(images, labels, noise, alpha)[0:1].clone()
+        noise = torch.randn((VB, 512), generator=gen).to(self.device)
+        alpha = torch.rand((VB,), generator=gen).to(self.device)
+        if self.val_step is None:
+            # the same variables at the validation batch size (train.py:199-203 feeds the validation iterator through the same graph)
+            self.val_step = GanStep(kernels_for(self.device), len(self.vocab), self.image_size, VB, lam=self.LAMBDA,
+                                    G=self.g._ensure(images), D=self.d._ensure(images))
+        self.step.flush()           # (a deferred optimiser step of the training networks changes the weights validation reads)
+        loss = self.val_step.critic_loss(images, labels, noise, alpha)[0:1].clone()
         if self.world > 1:
             torch.distributed.all_reduce(loss)
             loss /= self.world
@@ -226,9 +230,13 @@ class SceneGraphGAN(object):
     def _saveModel(self):
         self.step.flush()
         if self.rank == 0:
+            stopper = getattr(self, "_stopper", None)
             torch.save({"itr": self.itr, "G": self.g.state_dict(), "D": self.d.state_dict(),
                         "G_adam": (self.step.G.m_flat.cpu(), self.step.G.v_flat.cpu(), self.step.G.adam_t),
-                        "D_adam": (self.step.D.m_flat.cpu(), self.step.D.v_flat.cpu(), self.step.D.adam_t)}, self._ckpt_path())
+                        "D_adam": (self.step.D.m_flat.cpu(), self.step.D.v_flat.cpu(), self.step.D.adam_t),
+                        # the validation state of the loop (train.py:358-384): last loss, consecutive increases, batches consumed
+                        "val": {"last": stopper.last if stopper else float("inf"), "count": stopper.count if stopper else 0,
+                                "history": list(getattr(self, "val_history", []))}}, self._ckpt_path())
 
     def _loadModel(self):
         ck = torch.load(self._ckpt_path(), map_location="cpu")
@@ -237,6 +245,7 @@ class SceneGraphGAN(object):
         for net, key in ((self.step.G, "G_adam"), (self.step.D, "D_adam")):
             net.m_flat.copy_(ck[key][0]); net.v_flat.copy_(ck[key][1]); net.adam_t = ck[key][2]
         self.itr = ck["itr"]
+        self._resumed_val = ck.get("val")
 
     ############################################################
     ## Training (train.py:341-388)
@@ -269,6 +278,11 @@ class SceneGraphGAN(object):
         B, t0, itr0 = self.BATCH_SIZE, time.time(), self.itr
         loader = self._prefetcher(self.itr, n_it) if self.dataset is not None else None
         stopper, self.stopped_early, self.val_history = ValidationEarlyStop(patience), False, []
+        rv = getattr(self, "_resumed_val", None)
+        if rv is not None:          # a resumed run carries on with the validation iterator and the early-stop counters where it stopped
+            stopper.last, stopper.count, self.val_history = rv["last"], rv["count"], [tuple(x) for x in rv["history"]]
+            self._resumed_val = None
+        self._stopper = stopper
         try:
             while self.itr < n_it:
                 images, labels = next(loader) if loader is not None else self._next_batch(self.itr)
@@ -347,9 +361,11 @@ class SceneGraphGAN(object):
             images, _ = self._next_batch(0)
             self._constructOps(images)
         self.step.flush()
-        B, K = self.BATCH_SIZE, kernels_for(self.device)
-        n_samples = self.TEST_BATCH_MULTIPLIER * self.TEST_BATCH_SIZE
-        passes = max(1, -(-n_samples // B))
+        K = kernels_for(self.device)
+        # TEST_BATCH_MULTIPLIER runs of TEST_BATCH_SIZE copies of the image (train.py:139-150, 311-318), at that batch size
+        B = max(1, self.TEST_BATCH_SIZE)
+        passes = self.TEST_BATCH_MULTIPLIER
+        n_samples = passes * B
         if items is not None:
             items = list(items)[:max_images]
         elif self.dataset is None:
