@@ -92,8 +92,14 @@ int sgg_conv_split_weights_frag16(const float* in, void* out, int taps, int N, i
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
                         const float* amax_x, const float* amax_w, float* tile_stats, const float* ln_stats, const float* ln_gamma,
-                        const float* ln_beta, void* stream);
-/* tile_stats (optional): the epilogue also writes (count, mean, M2, max |y - mean|) of every output tile, [B][n][4] with
+                        const float* ln_beta, int operand_format, void* stream);
+/* operand_format (sgg_conv2d_nhwc_fwd / _dgrad: 0 or 1; _wgrad: bit 0 = x, bit 1 = dy): 1 = the operand is a PRE-SPLIT tensor as
+ * sgg_layernorm_hwc_elu_fwd / _bwd write it with out_format 1 - same shape and bytes as the f32 tensor, every aligned group of 32
+ * channels (128 B) holding the 32 leading fp16 pieces (64 B) then the 32 residual pieces of x * 2^e, e from the tensor's amax word
+ * (which must be the word the producer used).  The kernel then stages the operand without splitting it again (bit-identical
+ * products).  Precision 1 / 2 and the resident kernels only (w_split_layout 1 .. 4; wgrad: where sgg_conv2d_nhwc_wgrad_resident
+ * says 1); not together with an LN prologue on that operand.
+ * tile_stats (optional): the epilogue also writes (count, mean, M2, max |y - mean|) of every output tile, [B][n][4] with
  * n = sgg_conv2d_nhwc_fwd_tile_stats(...) > 0; pass them to sgg_layernorm_hwc_elu_fwd to skip its statistics pass, or to
  * sgg_layernorm_hwc_finalize when the consumer applies the LayerNorm itself:
  * LN prologue (ln_stats / ln_gamma / ln_beta, optional, w_split_layout 1 only; also on sgg_conv2d_nhwc_wgrad where its halo-resident
@@ -105,14 +111,16 @@ int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int KH, in
 /* Conv2DBackpropInput: dx from dy and the HWIO kernel */
 int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w_hwio, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
-                          const float* amax_dy, const float* amax_w, void* stream);
+                          const float* amax_dy, const float* amax_w, int operand_format, void* stream);
 /* Conv2DBackpropFilter: dw (HWIO) from x and dy.  algo: 0 = automatic (halo-resident kernel where it applies), 1 = per-tap
  * kernels only (A/B measurements). */
 size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW);
 int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B, int Hi, int Wi, int Cin, int Ho,
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int algo,
                           const float* amax_x, const float* amax_dy, const float* ln_stats, const float* ln_gamma, const float* ln_beta,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          int operand_format, void* workspace, size_t workspace_bytes, void* stream);
+/* 1 if the halo-resident filter-gradient kernel serves this shape with algo 0 (the kernel that takes pre-split operands) */
+int sgg_conv2d_nhwc_wgrad_resident(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision);
 
 /* ---- tf.contrib.layers.layer_norm(activation_fn=tf.nn.elu) over (H,W,C) per sample ------------------------
  * generator_with_attention.py:30..66 / discriminator_with_attention.py:30..66.  C: power of two in [4,1024].
@@ -127,15 +135,22 @@ size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C);
  * tile_stats must be NULL with W > 0. */
 int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
                               float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
-                              int W, int y0, int x0, int Hv, int Wv, void* workspace, size_t workspace_bytes, void* stream);
+                              int W, int y0, int x0, int Hv, int Wv, int out_format, void* workspace, size_t workspace_bytes, void* stream);
+/* out_format 1 (both directions): the output tensor (a / dy) is written PRE-SPLIT for the convolutions that consume it (see
+ * operand_format of sgg_conv2d_nhwc_fwd): every aligned 32-channel group as 32 leading + 32 residual fp16 pieces of x * 2^e.  The
+ * scale must be fixed before the tensor is written, so *amax_out (required, C % 32 == 0) then receives an upper BOUND of max|x|
+ * instead of the maximum: forward - the caller zeroes the word, the call merges the statistics, publishes max over the samples of
+ * max|gamma| * max|y - mean| * rstd + max|beta| and applies (three launches; two with tile_stats); backward - max(rstd * max|dxhat|) *
+ * (2 + max|xhat|), the two maxima published atomically by the reduction pass into the caller-zeroed words pq. */
 /* statistics only: stats[b] = (mean, rstd) merged from the convolution's tile partials; amax_out max-ed with an upper bound of
  * max|ELU(LN(y))| (for the fp16 scaling of a consumer with an LN prologue) */
 int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_stats, const float* gamma, const float* beta, float* stats,
                                float* amax_out, int B, int HW, int C, void* stream);
 int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
                               const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
-                              float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* workspace,
-                              size_t workspace_bytes, void* stream);
+                              float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, int out_format,
+                              float* pq /* out_format 1: two words, zeroed by the caller, for the maxima the bound is made of */,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* dgamma == dbeta == NULL in sgg_layernorm_hwc_elu_bwd DEFERS the parameter-gradient reductions (dgamma, dbeta, dbias_prev): the
  * partial sums stay in `workspace` (give every layer its own), and one launch of sgg_layernorm_hwc_bwd_finalize reduces up to 16

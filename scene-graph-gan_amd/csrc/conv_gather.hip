@@ -813,8 +813,11 @@ extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout,
 extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi,
                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l,
                                    int precision, int w_split_layout, const float* amax_x, const float* amax_w, float* tile_stats,
-                                   const float* ln_stats, const float* ln_gamma, const float* ln_beta, void* stream) {
+                                   const float* ln_stats, const float* ln_gamma, const float* ln_beta, int operand_format, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
+  SGG_CHECK_ARG(operand_format == 0 || (operand_format == 1 && sgg_prec_half(precision) && w_split_layout >= 1 && w_split_layout <= 4 &&
+                                        !ln_stats && Cin != 3),
+                "sgg_conv2d_nhwc_fwd: a pre-split (S16) x needs precision 1 / 2, a resident kernel (w_split_layout 1 .. 4) and no LN prologue");
   SGG_CHECK_ARG(!ln_stats || (w_split_layout >= 1 && w_split_layout <= 4 && ln_gamma && ln_beta && Cin <= 512),
                 "sgg_conv2d_nhwc_fwd: the LN prologue needs w_split_layout 1 .. 4 (resident kernels), gamma, beta and Cin <= 512");
   SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6, "sgg_conv2d_nhwc_fwd: precision must be 0, 1, 2, 3, 4 or 6");
@@ -849,6 +852,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
     sgg_halo_dense_strides(h);
     h.frag16 = w_split_layout == 4;
+    h.src_s16 = operand_format & 1;
     SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(halo)");
@@ -868,6 +872,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     sgg_halo_dense_strides(h);
     h.in_rs = 2 * Wi * Cin; h.in_ps = 2 * Cin; h.in_cA = Wi * Cin; h.in_cB = Cin;     // chunk (qy, qx): x[2a + qy][2c + qx][0..32)
     h.ln_nc = Cin;
+    h.src_s16 = operand_format & 1;
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(s2d)");
     return SGG_OK;
@@ -885,6 +890,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cin; q.N = Cout; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo;
     q.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
+    q.src_s16 = operand_format & 1;
     sgg_s2_launch(q, 0, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(s2)");
     return SGG_OK;
@@ -914,8 +920,10 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
 // dgrad: dx[B,Hi,Wi,Cin] = conv-transpose of dy[B,Ho,Wo,Cout] with the HWIO kernel w (no bias).
 extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void* w_split, float* dx, int B, int Hi, int Wi, int Cin, int Ho,
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision,
-                                     int w_split_layout, const float* amax_dy, const float* amax_w, void* stream) {
+                                     int w_split_layout, const float* amax_dy, const float* amax_w, int operand_format, void* stream) {
   SGG_CHECK_ARG(dy && w && dx, "sgg_conv2d_nhwc_dgrad: null pointer");
+  SGG_CHECK_ARG(operand_format == 0 || (operand_format == 1 && sgg_prec_half(precision) && w_split_layout >= 1 && w_split_layout <= 4),
+                "sgg_conv2d_nhwc_dgrad: a pre-split (S16) dy needs precision 1 / 2 and a resident kernel (w_split_layout 1 .. 4)");
   SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6, "sgg_conv2d_nhwc_dgrad: precision must be 0, 1, 2, 3, 4 or 6");
   SGG_CHECK_ARG(!sgg_prec_half(precision) || (amax_dy && amax_w), "sgg_conv2d_nhwc_dgrad: precision 1 / 2 need the amax words");
   SGG_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && stride >= 1 && stride <= 2, "sgg_conv2d_nhwc_dgrad: bad dims");
@@ -937,6 +945,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     h.w_bytes = (unsigned)((size_t)9 * Cin * Cout * sizeof(float));
     sgg_halo_dense_strides(h);
     h.frag16 = w_split_layout == 4;
+    h.src_s16 = operand_format & 1;
     sgg_halo_launch(h, precision, (hipStream_t)stream);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(halo)");
     return SGG_OK;
@@ -954,6 +963,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     h.w_bytes = (unsigned)((size_t)9 * 4 * Cin * Cout * sizeof(float));
     sgg_halo_dense_strides(h);
     h.out_rs = 2 * Wi * Cin; h.out_ps = 2 * Cin; h.out_nA = Wi * Cin; h.out_nB = Cin;  // group (qy, qx) -> dx[2a + qy][2c + qx][0..32)
+    h.src_s16 = operand_format & 1;
     sgg_halo_launch(h, precision, (hipStream_t)stream);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(s2d)");
     return SGG_OK;
@@ -971,6 +981,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     q.B = B; q.Ho = Ho; q.Wo = Wo; q.C = Cout; q.N = Cin; q.M = B * Ho * Wo; q.nbands = sgg_cdiv(q.M, 224); q.pitch = Wo;
     q.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
+    q.src_s16 = operand_format & 1;
     sgg_s2_launch(q, 1, precision, (hipStream_t)stream);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(s2)");
     return SGG_OK;

@@ -30,12 +30,14 @@ struct HaloParams {
   int out_rs, out_ps, out_nA, out_nB;
   int ln_nc;              // LN prologue: real channels of the source (a power of two: C, or 32 for the space-to-depth view)
   int frag16;             // 1: wfrag holds the fragments of the K = 32 MFMA shape (w_split_layout 4): the producer / consumer kernel
+  int src_s16;            // 1: src is a pre-split ("S16") tensor of the LayerNorm kernels (split16.h): staged without arithmetic
 };
 inline void sgg_halo_dense_strides(HaloParams& h) {
   h.in_rs = h.W * h.C; h.in_ps = h.C; h.in_cA = 64; h.in_cB = 32;
   h.out_rs = h.W * h.N; h.out_ps = h.N; h.out_nA = 64; h.out_nB = 32;
   h.ln_nc = h.C;
   h.frag16 = 0;
+  h.src_s16 = 0;
 }
 
 // 1 if the halo kernel serves a 3x3 / stride-1 convolution over an H x W grid in this precision
@@ -66,10 +68,25 @@ struct WgradHaloPlan {
 // H % 8 == W % 8 == 0, or - channels % 64 == 0 - any H with W <= 28: row bands)
 int sgg_wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradHaloPlan* pl);
 // writes pl.nslabs partial dW slabs [slab][9][Cin][Cout] (unscaled f32) into `slabs`
+// operand_format: bit 0 = x, bit 1 = dy is a pre-split ("S16") tensor (split16.h)
 void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,
                            int pad_t, int pad_l, int precision, const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl,
                            hipStream_t st, const float* ln_stats = nullptr, const float* ln_gamma = nullptr,
-                           const float* ln_beta = nullptr);
+                           const float* ln_beta = nullptr, int operand_format = 0);
+
+// ---- filter gradient on pre-split operands staged by LDS-DMA (conv_wgrad_dma.hip) ---------------------------------------------
+struct WgradDmaPlan {
+  int nt;               // 32-column output tiles of a workgroup: 4 (64 x 128 channel tile) or 2 (64 x 64, two pixel halves)
+  int spw;              // partial slabs a workgroup writes
+  int pairs, pairs_n;   // channel tiles; Cout tiles
+  int nsplit, stages, nslabs;
+  size_t ws_bytes;
+};
+// returns 1 and fills the plan if the shape is served (H, W = the dy grid, divisible by 8; 3x3 stride 1 or 5x5 stride 2; channels % 64 == 0)
+int sgg_wgrad_dma_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradDmaPlan* pl);
+// x, dy: pre-split ("S16") tensors; writes pl.nslabs partial dW slabs [slab][taps][Cin][Cout] (unscaled f32) into `slabs`
+void sgg_wgrad_dma_launch(const void* x, const void* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride, int pad_t,
+                          int pad_l, const float* amax_x, const float* amax_dy, const WgradDmaPlan& pl, hipStream_t st);
 
 // ---- band-resident 5x5 stride-2 convolution, forward and dgrad (conv_s2.hip) -----------------------------------------
 struct S2Params {
@@ -92,6 +109,7 @@ struct S2Params {
   int pitch;              // Wo: slots per patch row (no halo columns: edge lanes read a zero slot)
   unsigned src_bytes, w_bytes;
   int gx;                 // workgroups per XCD (set by sgg_s2_launch)
+  int src_s16;            // 1: src is a pre-split ("S16") tensor (split16.h)
   int ksplit;             // 1, or 2: two workgroups per (band, n-tile), each contracting half of the channel chunks and ADDING its
                           // partial into the zeroed output (a + b = b + a: still deterministic); set by sgg_s2_launch
 };

@@ -176,8 +176,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
       const bool bad = !((it_meta[j] >> 28) & 1) | ((((it_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
       const unsigned off = bad ? SGG_OOB : b0 + it_rel[j];
       if constexpr (LNP) ld_bad |= (int)bad << j;
-      pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
-      pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
+      const unsigned o0 = LNP ? off : stage_off0(off, p.src_s16);
+      pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, o0);
+      pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, LNP ? off + 16u : stage_off1(o0, p.src_s16));
     }
     if (++s_cc == nch) {        // advance to this workgroup's next tile
       s_cc = 0;
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_halo3_kernel(HaloParam
         ln_elu8(pre[j][0], pre[j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (ld_bad >> j) & 1);
       }
       u32x4 pl[P];
-      split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
+      if constexpr (LNP || !HALF) split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
+      else stage_planes<P, HALF>(pre[j][0], pre[j][1], sa, p.src_s16, pl);
       if ((it_meta[j] >> 28) & 1) {
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PLANEB + (it_meta[j] & 0xfffff)) = pl[pp];

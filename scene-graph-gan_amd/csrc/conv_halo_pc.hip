@@ -45,11 +45,14 @@ __device__ __forceinline__ int pc_sw(int ry, int rx) { return ((rx ^ (ry >> 1)) 
 
 typedef __attribute__((address_space(3))) void* pc_lds_ptr;
 
-template <bool HALF, bool LNP>
+// DMAP: the source is a PRE-SPLIT tensor (split16.h; HALF, no LN prologue): the producers stage the patch by LDS-DMA as well - no
+// staging registers, no vector arithmetic at all on the SIMDs the MFMA waves run on.
+template <bool HALF, bool LNP, bool DMAP = false>
 __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
+  static_assert(!DMAP || (HALF && !LNP), "patch DMA: pre-split fp16 pieces, no prologue");
   // ONE __shared__ object: with the LayerNorm parameters in an array of their own the compiler waits vmcnt(0) - for every weight DMA
   // in flight - in front of each patch write (cdna_hip_programming.md, "a second __shared__ object beside the glds staging array")
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PC_PATCHB + PC_D * PC_SLOTB + (LNP ? 4096 : 0)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PC_PATCHB + PC_D * PC_SLOTB + (LNP ? 4096 : 0) + (DMAP ? 1024 : 0)];
   unsigned char* const ring = lds + 2 * PC_PATCHB;
   float* const lnp_s = reinterpret_cast<float*>(lds + 2 * PC_PATCHB + PC_D * PC_SLOTB);      // gamma[0..511], beta at +512 (C <= 512: host check)
 
@@ -149,8 +152,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         const bool bad = !((it_meta[j] >> 28) & 1) | ((((it_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
         const unsigned off = bad ? SGG_OOB : b0 + it_rel[j];
         if constexpr (LNP) ld_bad[S] |= (int)bad << j;
-        pre[S][j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
-        pre[S][j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
+        const unsigned o0 = LNP ? off : stage_off0(off, p.src_s16);
+        pre[S][j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, o0);
+        pre[S][j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, LNP ? off + 16u : stage_off1(o0, p.src_s16));
       }
       if (++s_cc == nch) {        // advance to this workgroup's next tile
         s_cc = 0;
@@ -181,13 +185,73 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     auto stage_write_pass = [&](auto s_c, auto j_c, unsigned char* dst) __attribute__((always_inline)) {
       constexpr int S = decltype(s_c)::value, j = decltype(j_c)::value;
       u32x4 pl[PC_P];
-      split8<PC_P, HALF>(pre[S][j][0], pre[S][j][1], sa, pl);
+      if constexpr (LNP || !HALF) split8<PC_P, HALF>(pre[S][j][0], pre[S][j][1], sa, pl);
+      else stage_planes<PC_P, HALF>(pre[S][j][0], pre[S][j][1], sa, p.src_s16, pl);
       // (passes 0 .. 2 cover items 0 .. 767: always valid; the last pass holds 32 items)
       if (j < PC_NPASS - 1 || ((it_meta[j] >> 28) & 1)) {
 #pragma unroll
         for (int pp = 0; pp < PC_P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PC_PLANEB + (it_meta[j] & 0xfffff)) = pl[pp];
       }
     };
+    // ---- DMAP: the patch of one chunk = 2 planes x 240 slots (two blocks of 10 rows x pitch 12) x 64 B = 30 DMA instructions of 16
+    // slots; wave pw issues instructions 8 pw .. 8 pw + 7 of the sequence [plane][15 + 1 filler] (the filler goes to a scratch KiB
+    // with out-of-range offsets: every wave issues exactly eight, so one vmcnt protocol serves all four).  Lane l of an instruction
+    // writes LDS position l & 3 of slot 16 q + (l >> 2), so it FETCHES the piece the swizzle puts there: (l & 3) ^ pc_sw(ry, rx).
+    unsigned dm_rel[8];
+    int dm_meta[8];             // bits 0..3 border bits, 4 block, 5 valid
+    auto patch_dma = [&](unsigned char* dstbuf) __attribute__((always_inline)) {
+      unsigned base[PC_NB];
+      int bbits[PC_NB];
+#pragma unroll
+      for (int j = 0; j < PC_NB; ++j) {
+        const bool dead = (s_tile >= mt_end) | (s_tile * PC_NB + j >= p.nblk);
+        base[j] = (unsigned)(((s_grow[j] * 8 - 1) * p.in_rs + (s_bx[j] * 8 - 1) * p.in_ps + (s_cc >> 1) * p.in_cA + (s_cc & 1) * p.in_cB) * 4);
+        bbits[j] = dead ? 15 : ((s_by[j] == 0) | ((s_by[j] == p.bh - 1) << 1) | ((s_bx[j] == 0) << 2) | ((s_bx[j] == p.bw - 1) << 3));
+        if (dead) base[j] = SGG_OOB;
+      }
+      const int plane = pw >> 1;
+      unsigned char* dst = dstbuf + plane * PC_PLANEB + (pw & 1) * 8 * 1024;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int blk = (dm_meta[k] >> 4) & 1;
+        const unsigned b0 = blk ? base[1] : base[0];
+        const int bb = blk ? bbits[1] : bbits[0];
+        const bool bad = !((dm_meta[k] >> 5) & 1) | (((dm_meta[k] & 15) & bb) != 0) | (b0 == SGG_OOB);
+        const unsigned off = bad ? SGG_OOB : b0 + dm_rel[k];
+        // (the 16th instruction of a plane does not exist: the waves with pw & 1 send their last one, all lanes invalid, to the scratch)
+        unsigned char* d = ((pw & 1) && k == 7) ? lds + sizeof(lds) - 1024 : dst + k * 1024;
+        // (the plane's byte offset as SCALAR offset: the immediate offset field would move the LDS address too, scripts/ubench/dma_oob.hip)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (pc_lds_ptr)d, 16, off, plane * 64, 0, 0);
+      }
+      if (++s_cc == nch) {        // advance to this workgroup's next tile
+        s_cc = 0;
+        s_tile += tstride;
+#pragma unroll
+        for (int j = 0; j < PC_NB; ++j) {
+          s_bx[j] += adv_cols;
+          s_grow[j] += adv_rows;
+          s_by[j] += adv_rows;
+          if (s_bx[j] >= p.bw) {
+            s_bx[j] -= p.bw;
+            ++s_grow[j];
+            ++s_by[j];
+          }
+          while (s_by[j] >= p.bh) s_by[j] -= p.bh;
+        }
+      }
+    };
+    if constexpr (DMAP) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int slot = 16 * (8 * (pw & 1) + k) + (lane >> 2);      // slot inside the plane: [block][row 0..9][pitch 12]
+        const int blk = slot >= 120 ? 1 : 0, r = slot - 120 * blk;
+        const int ry = r / PC_PITCH, rx = r - ry * PC_PITCH;
+        const bool valid = slot < 240 && rx < 10;
+        const int piece = (lane & 3) ^ pc_sw(ry, rx);
+        dm_rel[k] = (unsigned)((ry * p.in_rs + rx * p.in_ps) * 4 + piece * 16);
+        dm_meta[k] = ((ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3)) | (blk << 4) | ((int)valid << 5);
+      }
+    }
     // ---- weight fragments: this wave moves pieces 4 pw .. 4 pw + 3 of the tap's sixteen 1-KiB pieces [n-tile 16][plane]
     const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
     const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * 4096u + (unsigned)lane * 16u;
@@ -214,7 +278,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    stage_load(std::integral_constant<int, 0>{});            // chunk 0
     auto full_pass = [&](auto s_c, auto j_c, unsigned char* dst) __attribute__((always_inline)) {
       if constexpr (LNP) {
         stage_ln_half(s_c, j_c, std::integral_constant<int, 0>{});
@@ -222,12 +285,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       }
       stage_write_pass(s_c, j_c, dst);
     };
-    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds);
-    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, lds);
-    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, lds);
-    full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, lds);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    stage_load(std::integral_constant<int, 1>{});            // chunk 1: in flight across the prologue barrier
+    if constexpr (DMAP) {
+      patch_dma(lds);                                        // chunk 0 (chunk c + 1 follows at tap 0 of chunk c, into the other buffer)
+      __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    } else {
+      stage_load(std::integral_constant<int, 0>{});            // chunk 0
+      full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds);
+      full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, lds);
+      full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, lds);
+      full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, lds);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      stage_load(std::integral_constant<int, 1>{});            // chunk 1: in flight across the prologue barrier
+    }
     __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 and the fragments of taps 0 .. 3 are in LDS
 
     // one tap of chunk c (register-set parity S = c & 1): T = 0 .. 8
@@ -236,11 +305,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       // (timing-only ablation builds, wrong results: -DPC_ABL_NOSTAGE no patch staging after the first, -DPC_ABL_NODMA no weight DMA
       //  after the prologue's, -DPC_ABL_NOEPI no output stores / statistics)
 #ifndef PC_ABL_NOSTAGE
+      if constexpr (DMAP) {
+        // the patch of chunk c + 1 straight into the buffer the consumers left at the last barrier: eight DMAs per wave, older than
+        // the weight DMAs of taps g + 3 .. (the same eight entries in the vmcnt queue as the register path's loads: same waits below;
+        // the vmcnt(8) of tap 3 retires them, five barriers before the consumers read that buffer)
+        if constexpr (T == 0) patch_dma(lds + (cur ^ 1) * PC_PATCHB);
+      } else
       if constexpr (T == 0) stage_load(s_c);                                    // chunk c + 2 -> set S (chunk c's data left it a chunk ago)
       // chunk c + 1 (set S ^ 1) -> the buffer the consumers do not read.  Without the LN prologue one pass (25 VALU) per tap at taps
       // 1 .. 4; with it half a pass per tap at taps 1 .. 8: the vector issue port of a SIMD is shared with the consumer wave, whose
       // 16x16x32 MFMAs alone hold it half of the time, and a whole pass of the prologue (16 v_exp) in one tap makes the barrier late
-      if constexpr (LNP) {
+      if constexpr (DMAP) {
+      } else if constexpr (LNP) {
         if constexpr (T >= 1) {
           constexpr int J = (T - 1) >> 1, HF = (T - 1) & 1;
           stage_ln_half(std::integral_constant<int, S ^ 1>{}, std::integral_constant<int, J>{}, std::integral_constant<int, HF>{});
@@ -500,6 +576,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
 #ifndef SGG_HALO_PC
 #define SGG_HALO_PC 1
 #endif
+#ifndef SGG_HALO_PC_DMA
+#define SGG_HALO_PC_DMA 1      // 0: a pre-split source is staged through registers (no arithmetic) like an f32 one
+#endif
 int sgg_halo_pc_applicable(int C, int N, int precision) {
   return SGG_HALO_PC && (precision == 2 || precision == 3) && N % 128 == 0 && C % 64 == 0 && C <= 512;
 }
@@ -513,6 +592,10 @@ void sgg_halo_pc_launch(const HaloParams& p_, int precision, hipStream_t st) {
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx)), blk(512);
   const bool half = precision == 2;
+  if (p.src_s16 && half && !p.ln_stats && SGG_HALO_PC_DMA) {      // pre-split source: the patch by LDS-DMA too
+    hipLaunchKernelGGL((conv_halo3_pc_kernel<true, false, true>), grid, blk, 0, st, p);
+    return;
+  }
   if (p.ln_stats) {
     if (half) hipLaunchKernelGGL((conv_halo3_pc_kernel<true, true>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((conv_halo3_pc_kernel<false, true>), grid, blk, 0, st, p);

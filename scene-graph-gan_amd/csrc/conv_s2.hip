@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
 #pragma unroll
     for (int j = 0; j < S2_NPASS; ++j) {
       const unsigned off = s_base[j] == SGG_OOB ? SGG_OOB : s_base[j] + uni;
-      pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off);
-      pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, off + 16u);
+      const unsigned o0 = LNP ? off : stage_off0(off, p.src_s16);
+      pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, o0);
+      pre[j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, LNP ? off + 16u : stage_off1(o0, p.src_s16));
       if constexpr (LNP) {
         ld_mu[j] = p.ln_stats[2 * s_b[j]];
         ld_rs[j] = p.ln_stats[2 * s_b[j] + 1];
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         ln_elu8(pre[j][0], pre[j][1], lnp_s + ch0, lnp_s + 512 + ch0, ld_mu[j], ld_rs[j], (ld_bad >> j) & 1);
       }
       u32x4 pl[P];
-      split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
+      if constexpr (LNP || !HALF) split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
+      else stage_planes<P, HALF>(pre[j][0], pre[j][1], sa, p.src_s16, pl);
       if (tid + 256 * j < 2 * S2_MAXSLOTS) {
         const int slot = (tid + 256 * j) >> 1;
         const int lds_off = slot * 32 + (((tid & 1) ^ S2_SWZ(slot)) << 4);

@@ -601,14 +601,30 @@ extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, i
   WgradHaloPlan hp;     // (precision and stride are not known here: upper bound over both kernels)
   const int st_guess = (Hi == Ho && Wi == Wo) ? 1 : ((Hi == 2 * Ho && Wi == 2 * Wo) ? 2 : 0);
   if (st_guess && Cin != 3 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, st_guess, &hp) && hp.ws_bytes > need) need = hp.ws_bytes;
+  WgradDmaPlan dp;
+  if (st_guess && Cin != 3 && sgg_wgrad_dma_plan(B, Ho, Wo, Cin, Cout, KH, KW, st_guess, &dp) && dp.ws_bytes > need) need = dp.ws_bytes;
   return need;
+}
+
+// 1: filter gradients whose operands are both pre-split run on the LDS-DMA kernel (conv_wgrad_dma.hip); 0 (-DSGG_WGRAD_DMA=0): always
+// the halo-resident kernel (which stages pre-split operands through registers without arithmetic)
+#ifndef SGG_WGRAD_DMA
+#define SGG_WGRAD_DMA 1
+#endif
+extern "C" int sgg_conv2d_nhwc_wgrad_resident(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision) {
+  WgradHaloPlan hp;
+  return sgg_prec_resident(precision) && Cin != 3 && B > 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp) ? 1 : 0;
 }
 
 extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,
                                      int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int algo,
                                      const float* amax_x, const float* amax_dy, const float* ln_stats, const float* ln_gamma,
-                                     const float* ln_beta, void* workspace, size_t workspace_bytes, void* stream) {
+                                     const float* ln_beta, int operand_format, void* workspace, size_t workspace_bytes, void* stream) {
   SGG_CHECK_ARG(x && dy && dw, "sgg_conv2d_nhwc_wgrad: null pointer");
+  SGG_CHECK_ARG(operand_format >= 0 && operand_format <= 3 && (operand_format == 0 || (sgg_prec_half(precision) && Cin != 3 && algo == 0)) &&
+                    !((operand_format & 1) && ln_stats),
+                "sgg_conv2d_nhwc_wgrad: pre-split (S16) operands need precision 1 / 2 and the halo-resident kernel (algo 0); x with an LN "
+                "prologue is the f32 pre-LayerNorm tensor");
   SGG_CHECK_ARG(!ln_stats || (ln_gamma && ln_beta), "sgg_conv2d_nhwc_wgrad: the LN prologue needs stats, gamma and beta");
   SGG_CHECK_ARG(algo == 0 || algo == 1, "sgg_conv2d_nhwc_wgrad: algo must be 0 (auto) or 1 (per-tap kernels only)");
   SGG_CHECK_ARG(precision == 0 || (precision >= 1 && precision <= 4) || precision == 6,
@@ -627,6 +643,20 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
     }
   }
   const long long nout = (long long)KH * KW * Cin * Cout;
+  WgradDmaPlan dp;
+  if (SGG_WGRAD_DMA && operand_format == 3 && precision == 2 && !ln_stats && algo == 0 && pad_t == 1 && pad_l == 1 && Hi == Ho * stride &&
+      Wi == Wo * stride && sgg_wgrad_dma_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &dp)) {
+    // both operands pre-split: staged by LDS-DMA, no staging arithmetic (conv_wgrad_dma.hip)
+    if (!workspace || workspace_bytes < dp.ws_bytes) {
+      sgg_set_error("sgg_conv2d_nhwc_wgrad: workspace too small (%zu < %zu)", workspace_bytes, dp.ws_bytes);
+      return SGG_ERR_WORKSPACE;
+    }
+    sgg_wgrad_dma_launch(x, dy, (float*)workspace, B, Ho, Wo, Cin, Cout, stride, pad_t, pad_l, amax_x, amax_dy, dp, st);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(dma)");
+    launch_slab_reduce((const float*)workspace, dw, nout / 4, dp.nslabs, st);
+    SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(dma reduce)");
+    return SGG_OK;
+  }
   WgradHaloPlan hp;
   if (sgg_prec_resident(precision) && Cin != 3 && pad_t == 1 && pad_l == 1 && Hi == Ho * stride && Wi == Wo * stride &&
       algo == 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp) && !(hp.geo == 1 && ln_stats)) {
@@ -636,12 +666,13 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
       return SGG_ERR_WORKSPACE;
     }
     sgg_wgrad_halo_launch(x, dy, (float*)workspace, B, Ho, Wo, Cin, Cout, stride, pad_t, pad_l, precision, amax_x, amax_dy, hp, st,
-                          ln_stats, ln_gamma, ln_beta);
+                          ln_stats, ln_gamma, ln_beta, operand_format);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo)");
     launch_slab_reduce((const float*)workspace, dw, nout / 4, hp.nslabs, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(halo reduce)");
     return SGG_OK;
   }
+  SGG_CHECK_ARG(operand_format == 0, "sgg_conv2d_nhwc_wgrad: pre-split (S16) operands are served by the halo-resident kernel only");
   SGG_CHECK_ARG(!ln_stats, "sgg_conv2d_nhwc_wgrad: the LN prologue is served by the halo-resident kernel only (3x3 stride 1 or 5x5 "
                            "stride 2 on grids divisible by 8, precision 2 or 3, algo 0)");
   if (Cin == 3) {

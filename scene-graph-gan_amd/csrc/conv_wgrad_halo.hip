@@ -64,6 +64,7 @@ struct WgradHaloParams {
   int pairs_n;            // Cout chunks
   int stages;             // stages per workgroup (NBS blocks each)
   unsigned x_bytes, dy_bytes;
+  int x_s16, dy_s16;      // 1: the operand is a pre-split ("S16") tensor of the LayerNorm kernels (split16.h)
 };
 
 // NKH x NKW: taps of the launch (3x3 for the stride-1 kernel; 3x3 / 3x2 / 2x3 / 2x2 for the four parity classes of a 5x5
@@ -204,12 +205,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
       }
       const unsigned off = bad ? SGG_OOB : (isx ? xbase : dbase) + rel;
       const int slot = (DY_LATE && !isx) ? jj - XP : jj;
+      const int fmt = isx ? p.x_s16 : p.dy_s16;
+      const unsigned o0 = stage_off0(off, fmt), o1 = stage_off1(o0, fmt);
       if (isx) {
-        pre[slot][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off);
-        pre[slot][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off + 16u);
+        pre[slot][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, o0);
+        pre[slot][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, o1);
       } else {
-        pre[slot][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off);
-        pre[slot][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off + 16u);
+        pre[slot][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, o0);
+        pre[slot][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, o1);
       }
     }
     if constexpr (part != 1) {
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
       if ((part == 1 && !isx) || (part == 2 && isx)) continue;
       const int slot = (DY_LATE && !isx) ? jj - XP : jj;
       u32x4 pl[P];
-      split8<P, HALF>(pre[slot][0], pre[slot][1], isx ? sa : sb, pl);
+      if constexpr (HALF) stage_planes<P, HALF>(pre[slot][0], pre[slot][1], isx ? sa : sb, isx ? p.x_s16 : p.dy_s16, pl);
+      else split8<P, HALF>(pre[slot][0], pre[slot][1], isx ? sa : sb, pl);
       unsigned rel;
       int meta;
       rb_plan(jj, rel, meta);
@@ -257,12 +261,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
         const bool bad = dead | !((it_lds[j] >> 24) & 1) | (isx && (((it_lds[j] >> 20) & 15 & bbits) != 0));
         if constexpr (LNP) ld_bad |= (int)bad << j;
         const unsigned off = bad ? SGG_OOB : (isx ? xbase : dbase) + it_rel[j];
+        const int fmt = isx ? (LNP ? 0 : p.x_s16) : p.dy_s16;
+        const unsigned o0 = stage_off0(off, fmt), o1 = stage_off1(o0, fmt);
         if (isx) {
-          pre[j][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off);
-          pre[j][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, off + 16u);
+          pre[j][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, o0);
+          pre[j][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_x, o1);
         } else {
-          pre[j][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off);
-          pre[j][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, off + 16u);
+          pre[j][0] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, o0);
+          pre[j][1] = buf_load4_aux<SGG_WGRAD_LOAD_AUX>(rs_dy, o1);
         }
       }
       // advance this slot to the next stage's block
@@ -290,7 +296,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo3_kernel(WgradHaloParam
       pl[0] = __builtin_bit_cast(u32x4, pre[j][0]);
       if constexpr (P == 2) pl[1] = __builtin_bit_cast(u32x4, pre[j][1]);
 #else
-      split8<P, HALF>(pre[j][0], pre[j][1], isx ? sa : sb, pl);
+      if constexpr (HALF) stage_planes<P, HALF>(pre[j][0], pre[j][1], isx ? sa : sb, isx ? (LNP ? 0 : p.x_s16) : p.dy_s16, pl);
+      else split8<P, HALF>(pre[j][0], pre[j][1], isx ? sa : sb, pl);
 #endif
       if ((it_lds[j] >> 24) & 1) {
         unsigned char* dst = (isx ? x_s : d_s) + (it_lds[j] & 0xfffff);
@@ -519,8 +526,9 @@ static void wgrad_halo_launch_class(const WgradHaloParams& p, const WgradHaloPla
 // stride: 1 (3x3) or 2 (5x5, one launch per parity class of the taps); pad_t / pad_l: SAME padding before
 void sgg_wgrad_halo_launch(const float* x, const float* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride,
                            int pad_t, int pad_l, int precision, const float* amax_x, const float* amax_dy, const WgradHaloPlan& pl,
-                           hipStream_t st, const float* ln_stats, const float* ln_gamma, const float* ln_beta) {
+                           hipStream_t st, const float* ln_stats, const float* ln_gamma, const float* ln_beta, int operand_format) {
   WgradHaloParams p;
+  p.x_s16 = operand_format & 1; p.dy_s16 = (operand_format >> 1) & 1;
   p.x = x; p.dy = dy; p.slabs = slabs; p.amax_x = amax_x; p.amax_dy = amax_dy;
   p.ln_stats = ln_stats; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.B = B;
   p.H = H; p.W = W; p.C = Cin; p.N = Cout; p.bh = H / 8; p.bw = W / 8; p.nblk = B * p.bh * p.bw;

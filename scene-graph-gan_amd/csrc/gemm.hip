@@ -282,6 +282,10 @@ static void gemm_wk_launch(const GemmParams& p, hipStream_t st) {
 }
 // the shapes that take it: NN / NT whose 64 x 64 tiling would split K over workgroups, M and K of the heads' size
 static bool gemm_wk_applicable(int mode, int M, int N, int K, int nsplit_old) {
+  // measured per shape (profiles/r04_gemm_wk_per_shape.log): 2 - 3 x faster on the small products (3.6 against 8.5 us), 20 % on
+  // M = 64 and M = 192 gate products; with 65 .. 128 rows and a large weight matrix its 16-column tiles re-read A once too often
+  // (20.0 against 16.2 us): those stay on the slab kernels
+  if (M > 64 && M <= 128 && (long long)N * K >= (1LL << 21)) return false;
   return SGG_GEMM_WK && mode != 2 && nsplit_old > 1 && M <= 512 && K <= 8192 && N >= 16;
 }
 

@@ -9,7 +9,20 @@
 //   forward : ln_stats_partial  -> ln_apply_elu
 //   backward: ln_bwd_partial    -> ln_bwd_finalize (dgamma, dbeta, bias grad of the producing conv)
 //                               -> ln_bwd_apply    (dy)
-#include "sgg_common.h"
+//
+// Pre-split outputs (out_format 1, "S16": split16.h).  Both outputs of this file are the next convolutions' MFMA operands (a: forward
+// and filter gradient of the next layer; dy: input and filter gradient of this one), and every consumer used to split the same f32
+// values into two fp16 pieces again while staging them - on the issue port of its MFMA waves.  These kernels are HBM-bound with the
+// VALU idle, so they can write the pieces instead: same bytes, each aligned 32-channel group as 32 leading + 32 residual pieces of
+// x * 2^e.  The scale has to be fixed BEFORE the tensor is written, so the tensor's amax word holds an upper BOUND of max|x| instead
+// of the maximum itself:
+//   a  : max|gamma| * max|y - mean| * rstd + max|beta| over the samples (ln_finalize_kernel, from the statistics partials);
+//   dy : max(rstd * max|dxhat|) * (2 + max|xhat|) (|mean dxhat| <= max|dxhat|, |mean dxhat xhat| <= max|dxhat| because
+//        mean xhat^2 <= 1): ln_bwd_partial publishes the two maxima atomically into two caller-zeroed words (pq), every workgroup
+//        of ln_bwd_apply derives the same bound from them, one of them publishes it.
+// A bound that is 2^k too large costs k of the 16 binades between the tensor's maximum and the point where the residual piece turns
+// subnormal (split16.h: an element 2^-d below the maximum keeps min(23, 39 - d) bits): nothing at the sizes that occur (k <= 4).
+#include "split16.h"
 
 #define LN_EPS 1e-12f
 #ifndef SGG_LN_WGS
@@ -234,10 +247,12 @@ template <bool MASK>
 __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __restrict__ y, const float* __restrict__ da,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ stats, float* __restrict__ sspart,
-                                                             float* __restrict__ chpart, long long N, int C, int G, int cpg,
-                                                             LnMask mk) {
+                                                             float* __restrict__ chpart, float* __restrict__ pq, long long N, int C,
+                                                             int G, int cpg, LnMask mk) {
   __shared__ float red[4];
   __shared__ float chs[256 * 12];
+  float mxd = 0.f, mxx = 0.f;          // max |dxhat|, max |xhat| of this workgroup's elements (the bound of max|dy|: file header)
+  // (computed unconditionally: two v_max per element in an HBM-bound kernel)
   const int b = blockIdx.y, g = blockIdx.x;
   const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
   const float* yb = y + (size_t)b * N;
@@ -266,14 +281,25 @@ __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __rest
         s1 += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
         const f32x4 t = dxh * xh;
         s2 += (t[0] + t[1]) + (t[2] + t[3]);
+        mxd = fmaxf(fmaxf(mxd, fmaxf(fabsf(dxh[0]), fabsf(dxh[1]))), fmaxf(fabsf(dxh[2]), fabsf(dxh[3])));
+        mxx = fmaxf(fmaxf(mxx, fmaxf(fabsf(xh[0]), fabsf(xh[1]))), fmaxf(fabsf(xh[2]), fabsf(xh[3])));
       }
     }
   }
   const float S1 = block_sum_256(s1, red);
   const float S2 = block_sum_256(s2, red);
+  mxd = wave_max(mxd);
+  mxx = wave_max(mxx);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { chs[threadIdx.x >> 6] = mxd; chs[4 + (threadIdx.x >> 6)] = mxx; }
+  __syncthreads();
   if (threadIdx.x == 0) {
     sspart[((size_t)b * G + g) * 2 + 0] = S1;
     sspart[((size_t)b * G + g) * 2 + 1] = S2;
+    if (pq) {      // (pre-split dy: the two maxima its bound is made of)
+      atomic_amax(pq, rstd * fmaxf(fmaxf(chs[0], chs[1]), fmaxf(chs[2], chs[3])));
+      atomic_amax(pq + 1, fmaxf(fmaxf(chs[4], chs[5]), fmaxf(chs[6], chs[7])));
+    }
   }
   // per-channel reduce across threads with equal (tid*4) % C
   __syncthreads();
@@ -436,6 +462,113 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
   if (amax_out) block_publish_amax(amax_out, amax, red);
 }
 
+// ---- pre-split ("S16") outputs -------------------------------------------------------------------------------------------
+// Same thread <-> element map as the f32 kernels (lane t holds 4 consecutive channels: perfectly coalesced 16-byte loads).  A lane's
+// four values make 8 bytes of leading and 8 bytes of residual pieces; lanes t and t ^ 1 hold the two halves of an 8-channel item, so
+// they swap one half each through a DPP quad permute (no LDS): the even lane then stores the item's 16 bytes of LEADING pieces, the odd
+// lane its 16 bytes of RESIDUAL pieces - one 16-byte store per lane, and the eight lanes of a 32-channel group write its whole
+// 128-byte line with one instruction.  EVERY lane of the wave calls this; `in`: the lane's channels exist (e < N; N % 8 == 0, so a
+// pair is in or out together).
+__device__ __forceinline__ unsigned s16_swap1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]: lane ^ 1
+}
+__device__ __forceinline__ void s16_store4(float* tensor_b, long long e, const f32x4& o, float scale, bool in) {
+  unsigned hi0, lo0, hi1, lo1;
+  f16_split2(o[0] * scale, o[1] * scale, hi0, lo0);
+  f16_split2(o[2] * scale, o[3] * scale, hi1, lo1);
+  const bool odd = (threadIdx.x & 1) != 0;
+  const unsigned r0 = s16_swap1(odd ? hi0 : lo0), r1 = s16_swap1(odd ? hi1 : lo1);
+  const u32x4 v = odd ? u32x4{r0, r1, lo0, lo1} : u32x4{hi0, hi1, r0, r1};
+  const long long eb = e * 4;
+  unsigned char* g = reinterpret_cast<unsigned char*>(tensor_b) + (eb & ~127LL) + ((eb & 127LL) >> 5) * 16 + (odd ? 64 : 0);
+  if (in) *reinterpret_cast<u32x4*>(g) = v;
+}
+
+// a = ELU(LN(y)) written pre-split; stats [B][2] and the bound in *amax are final (ln_finalize_kernel ran before)
+template <bool MASK>
+__global__ __launch_bounds__(256) void ln_apply_elu_s16_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ stats,
+                                                               float* __restrict__ a, long long N, int C, int cpg,
+                                                               const float* __restrict__ amax, LnMask mk) {
+  const int b = blockIdx.y, g = blockIdx.x;
+  const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
+  const float scale = ldexpf(1.f, scale_exp_from_amax(*amax));
+  const float* yb = y + (size_t)b * N;
+  float* ab = a + (size_t)b * N;
+  const int ch = (threadIdx.x * 4) % C;   // constant across chunks: LN_CHUNK and 1024 are multiples of C
+  const f32x4 inv = *reinterpret_cast<const f32x4*>(gamma + ch) * rstd;
+  const f32x4 shift = *reinterpret_cast<const f32x4*>(beta + ch) - inv * mean;
+  for (int c = 0; c < cpg; ++c) {
+    const long long base = ((long long)g * cpg + c) * LN_CHUNK;
+    if (base >= N) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = base + (threadIdx.x + 256 * j) * 4;
+      const bool in = e < N;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (in && (!MASK || ln_valid(mk, e))) {
+        const f32x4 v = ln_ld(yb + e);
+        o = v * inv + shift;
+        o[0] = elu1(o[0]); o[1] = elu1(o[1]); o[2] = elu1(o[2]); o[3] = elu1(o[3]);
+      }
+      s16_store4(ab, e, o, scale, in);
+    }
+  }
+}
+
+// dy of the LayerNorm backward written pre-split.  pq[0] = max over all workgroups of ln_bwd_partial of rstd * max|dxhat|, pq[1] =
+// their max|xhat| (atomic maxima, the words zeroed by the caller): bound = pq[0] * (2 + pq[1]) >= max|dy| (file header; the two
+// maxima may come from different samples: only looser).  Workgroup (0, 0) publishes the bound in *amax_out for the consumers.
+template <bool MASK>
+__global__ __launch_bounds__(256) void ln_bwd_apply_s16_kernel(const float* __restrict__ y, const float* __restrict__ da,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ stats, const float* __restrict__ sspart,
+                                                               const float* __restrict__ pq, float* __restrict__ dy, long long N,
+                                                               int C, int G, int cpg, float* __restrict__ amax_out, LnMask mk,
+                                                               float nvalid) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, g = blockIdx.x;
+  const float bound = 1.0001f * pq[0] * (2.f + pq[1]);
+  if (amax_out && b == 0 && g == 0 && threadIdx.x == 0) *amax_out = bound;
+  const float scale = ldexpf(1.f, scale_exp_from_amax(bound));
+  const float mean = stats[b * 2 + 0], rstd = stats[b * 2 + 1];
+  float a1 = 0.f, a2 = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) {
+    a1 += sspart[((size_t)b * G + i) * 2 + 0];
+    a2 += sspart[((size_t)b * G + i) * 2 + 1];
+  }
+  const float m1 = block_sum_256(a1, red) / (MASK ? nvalid : (float)N);
+  const float m2 = block_sum_256(a2, red) / (MASK ? nvalid : (float)N);
+  const float* yb = y + (size_t)b * N;
+  const float* db = da + (size_t)b * N;
+  float* ob = dy + (size_t)b * N;
+  const int ch = (threadIdx.x * 4) % C;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + ch);
+  const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + ch);
+  for (int c = 0; c < cpg; ++c) {
+    const long long base = ((long long)g * cpg + c) * LN_CHUNK;
+    if (base >= N) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = base + (threadIdx.x + 256 * j) * 4;
+      const bool in = e < N;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (in && (!MASK || ln_valid(mk, e))) {
+        const f32x4 v = ln_ld(yb + e);
+        const f32x4 d = ln_ld(db + e);
+        const f32x4 xh = (v - mean) * rstd;
+        const f32x4 n = xh * gm + bt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float dn = d[q] * (n[q] > 0.f ? 1.f : __expf(n[q]));
+          o[q] = rstd * (dn * gm[q] - m1 - xh[q] * m2);
+        }
+      }
+      s16_store4(ob, e, o, scale, in);
+    }
+  }
+}
+
 // ---- host ----------------------------------------------------------------------------------------------
 extern "C" size_t sgg_layernorm_hwc_elu_workspace_bytes(int B, int HW, int C) {
   const LnGeom g = ln_geom(B, HW, C);
@@ -471,8 +604,10 @@ static int ln_mask(const char* name, int HW, int C, int W, int y0, int x0, int H
 // convolution's partials cover the whole canvas.)
 extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* beta, float* a, float* stats,
                                          float* amax_out, const float* tile_stats, int n_tile_stats, int B, int HW, int C,
-                                         int W, int y0, int x0, int Hv, int Wv, void* ws, size_t ws_bytes, void* stream) {
+                                         int W, int y0, int x0, int Hv, int Wv, int out_format, void* ws, size_t ws_bytes, void* stream) {
   SGG_CHECK_ARG(y && gamma && beta && a && stats, "sgg_layernorm_hwc_elu_fwd: null pointer");
+  SGG_CHECK_ARG(out_format == 0 || (out_format == 1 && amax_out && C % 32 == 0),
+                "sgg_layernorm_hwc_elu_fwd: out_format 1 (pre-split output) needs the amax word (zeroed by the caller) and C %% 32 == 0");
   int rc = ln_check("sgg_layernorm_hwc_elu_fwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
   LnMask mk;
@@ -480,6 +615,29 @@ extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, con
   if ((rc = ln_mask("sgg_layernorm_hwc_elu_fwd", HW, C, W, y0, x0, Hv, Wv, mk, nvalid))) return rc;
   const LnGeom g = ln_geom(B, HW, C);
   hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  if (out_format == 1) {
+    // statistics (from the convolution's partials, or a pass of our own) -> stats + the bound of max|a| in *amax_out -> apply
+    const float* parts = tile_stats;
+    int nparts = n_tile_stats;
+    if (!(tile_stats && n_tile_stats > 0)) {
+      if (W == 0) hipLaunchKernelGGL(ln_stats_partial_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg, mk);
+      else hipLaunchKernelGGL(ln_stats_partial_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg, mk);
+      parts = part;
+      nparts = g.G;
+    } else {
+      SGG_CHECK_ARG(W == 0, "sgg_layernorm_hwc_elu_fwd: tile_stats cannot be combined with a valid region");
+    }
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(B), dim3(256), 0, st, parts, nparts, nvalid, gamma, beta, C, stats, amax_out);
+    if (W == 0)
+      hipLaunchKernelGGL(ln_apply_elu_s16_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)stats, a, g.N, C,
+                         g.cpg, (const float*)amax_out, mk);
+    else
+      hipLaunchKernelGGL(ln_apply_elu_s16_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)stats, a, g.N, C,
+                         g.cpg, (const float*)amax_out, mk);
+    SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_fwd");
+    return SGG_OK;
+  }
   if (tile_stats && n_tile_stats > 0) {
     SGG_CHECK_ARG(W == 0, "sgg_layernorm_hwc_elu_fwd: tile_stats cannot be combined with a valid region");
     hipLaunchKernelGGL(ln_apply_elu_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, tile_stats, a, stats, g.N, C,
@@ -487,7 +645,6 @@ extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, con
     SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_fwd");
     return SGG_OK;
   }
-  float* part = (float*)ws;
   if (W == 0) {
     hipLaunchKernelGGL(ln_stats_partial_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, part, g.N, g.G, g.cpg, mk);
     hipLaunchKernelGGL(ln_apply_elu_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, gamma, beta, (const float*)part, a, stats,
@@ -514,9 +671,12 @@ extern "C" int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_st
 
 extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamma, const float* beta,
                                          const float* stats, float* dy, float* dgamma, float* dbeta, float* dbias_prev,
-                                         float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, void* ws,
-                                         size_t ws_bytes, void* stream) {
+                                         float* amax_out, int B, int HW, int C, int W, int y0, int x0, int Hv, int Wv, int out_format,
+                                         float* pq, void* ws, size_t ws_bytes, void* stream) {
   SGG_CHECK_ARG(y && da && gamma && beta && stats && dy && (!dgamma == !dbeta), "sgg_layernorm_hwc_elu_bwd: null pointer");
+  SGG_CHECK_ARG(out_format == 0 || (out_format == 1 && amax_out && pq && C % 32 == 0),
+                "sgg_layernorm_hwc_elu_bwd: out_format 1 (pre-split output) needs the amax word, two zeroed words pq and C %% 32 == 0");
+  if (out_format == 0) pq = nullptr;
   int rc = ln_check("sgg_layernorm_hwc_elu_bwd", B, HW, C, ws_bytes, ws);
   if (rc) return rc;
   LnMask mk;
@@ -530,13 +690,23 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
   const int hw_valid = W == 0 ? HW : Hv * Wv;
   if (W == 0)
     hipLaunchKernelGGL(ln_bwd_partial_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart,
-                       g.N, C, g.G, g.cpg, mk);
+                       pq, g.N, C, g.G, g.cpg, mk);
   else
     hipLaunchKernelGGL(ln_bwd_partial_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart,
-                       g.N, C, g.G, g.cpg, mk);
+                       pq, g.N, C, g.G, g.cpg, mk);
   if (dgamma)      // (NULL: the caller reduces the partials later, several layers at once: sgg_layernorm_hwc_bwd_finalize)
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sspart,
                        (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, hw_valid);
+  if (out_format == 1) {
+    if (W == 0)
+      hipLaunchKernelGGL(ln_bwd_apply_s16_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, (const float*)sspart,
+                         (const float*)pq, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
+    else
+      hipLaunchKernelGGL(ln_bwd_apply_s16_kernel<true>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, (const float*)sspart,
+                         (const float*)pq, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);
+    SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd");
+    return SGG_OK;
+  }
   if (W == 0)
     hipLaunchKernelGGL(ln_bwd_apply_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats,
                        (const float*)sspart, dy, g.N, C, g.G, g.cpg, amax_out, mk, nvalid);

@@ -64,6 +64,29 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float s
   }
 }
 
+// ---- pre-split activations ("S16" tensors) -------------------------------------------------------------------------------
+// The LayerNorm kernels can write their outputs (a = ELU(LN(y)); dy of the LayerNorm backward) already split: the tensor keeps
+// its NHWC shape and byte size, but every aligned group of 32 channels (128 B) holds the 32 LEADING fp16 pieces (64 B) followed
+// by the 32 RESIDUAL pieces (64 B) of x * 2^e = hi + lo - exactly what split8<2, true> produces, with e = scale_exp_from_amax of
+// the tensor's amax word, which then holds an upper BOUND of max|x| fixed before the tensor is written (sgg_layernorm_hwc_*).
+// A consumer stages such an operand without arithmetic: two 16-byte loads (pieces of 8 channels) go to the two LDS planes as they
+// are.  Given the byte offset `off` of 8 consecutive channels in the f32 layout (32-byte aligned, inside one 128-byte group):
+__device__ __forceinline__ unsigned s16_hi_off(unsigned off) { return (off & ~127u) | ((off & 127u) >> 1); }     // lo pieces: + 64
+// (SGG_OOB stays out of range: its low seven bits are zero.)
+// second load of an 8-channel item: the next 4 floats, or the residual pieces
+__device__ __forceinline__ unsigned stage_off0(unsigned off, int s16) { return s16 ? s16_hi_off(off) : off; }
+__device__ __forceinline__ unsigned stage_off1(unsigned off0, int s16) { return off0 + (s16 ? 64u : 16u); }
+// 8 staged channels -> P planes: the split of f32 data, or the two loaded registers as they are
+template <int P, bool HALF>
+__device__ __forceinline__ void stage_planes(const f32x4& v0, const f32x4& v1, float scale, int s16, u32x4 (&pl)[P]) {
+  if (s16) {
+    pl[0] = __builtin_bit_cast(u32x4, v0);
+    if constexpr (P == 2) pl[1] = __builtin_bit_cast(u32x4, v1);
+  } else {
+    split8<P, HALF>(v0, v1, scale, pl);
+  }
+}
+
 template <bool HALF>
 __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 c) {
   if constexpr (HALF)

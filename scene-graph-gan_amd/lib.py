@@ -35,14 +35,15 @@ SIGNATURES = {
     "sgg_conv_prepare_weights": (_i, [_vp, _i, _i, _vp]),
     "sgg_conv_split_weights_frag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sgg_conv_split_weights_frag16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
-    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp]),
+    "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _i, _vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
-    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sgg_conv2d_nhwc_wgrad_resident": (_i, [_i] * 9),
     "sgg_layernorm_hwc_elu_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 9 + [_vp, _sz, _vp]),
-    "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_fwd": (_i, [_vp] * 7 + [_i] * 10 + [_vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_bwd": (_i, [_vp] * 10 + [_i] * 9 + [_vp, _vp, _sz, _vp]),
     "sgg_layernorm_hwc_bwd_finalize": (_i, [_vp, _i, _vp]),
     "sgg_layernorm_hwc_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgg_spatial_mean_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -150,10 +151,14 @@ DEFAULT_OPTIONS = {
     # (trunk._plan_ln_fusion: 28 of the 44 apply passes of a step at configs[1]); 2 = wherever the kernels allow (slower:
     # DESIGN.md); 0 = never
     "ln_fusion": 1,
-    # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward
+    # True: the LayerNorm kernels write their outputs pre-split for the convolutions that consume them (trunk._plan_s16; fp16 modes)
+    "presplit": True,
+    # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward /
+    # never fuse in passes with backward
     "ln_fusion_skip": (),
     "ln_fusion_force": (),
     "ln_fusion_force_bwd": (),
+    "ln_fusion_skip_bwd": (),
 }
 
 
@@ -370,10 +375,11 @@ class HipKernels:
                                                    "true" if self.conv_precision in (1, 4) else "false", "true" if lnp else "false")
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0,
-                 ln=None):
+                 ln=None, x_s16=False):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3).
         ln = (stats [B,2], gamma, beta): x is the producing layer's PRE-LayerNorm output; the kernel applies LN + ELU while staging
-        (halo-resident kernel only; amax_x = the word ln_finalize published)."""
+        (halo-resident kernel only; amax_x = the word ln_finalize published).
+        x_s16: x is a pre-split tensor (ln_elu_fwd(..., out_s16=True); amax_x = the word that call published)."""
         self._dev(x, w_fwd, bias, y)
         ln_s, ln_g, ln_b = ln if ln is not None else (None, None, None)
         self._dev(ln_s, ln_g, ln_b)
@@ -392,9 +398,10 @@ class HipKernels:
             nb = 4.0 * (x.numel() + y.numel())      # conv1_1 (K = 27) is HBM-bound: the image read once, y written once
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
             _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, w_split_layout, _p(amax_x), _p(amax_w),
-            _p(tile_stats), _p(ln_s), _p(ln_g), _p(ln_b), self._stream()), nb), "sgg_conv2d_nhwc_fwd")
+            _p(tile_stats), _p(ln_s), _p(ln_g), _p(ln_b), int(bool(x_s16)), self._stream()), nb), "sgg_conv2d_nhwc_fwd")
 
-    def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None, w_split_layout=0):
+    def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None, w_split_layout=0, dy_s16=False):
+        """dy_s16: dy is a pre-split tensor (ln_elu_bwd(..., out_s16=True); amax_dy = the word that call published)."""
         self._dev(dy, w_hwio, dx)
         d = self._conv_dims(dx.shape, w_hwio.shape, stride)
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
@@ -405,10 +412,15 @@ class HipKernels:
                                                                           self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),
-            self._stream())), "sgg_conv2d_nhwc_dgrad")
+            int(bool(dy_s16)), self._stream())), "sgg_conv2d_nhwc_dgrad")
 
-    def conv_wgrad(self, x, dy, dw, stride, amax_x=None, amax_dy=None, ln=None):
-        """ln: as conv_fwd (x = pre-LayerNorm output of the producing layer; halo-resident wgrad kernel only)."""
+    def wgrad_resident(self, B, Ho, Wo, cin, cout, k, stride):
+        """True if conv_wgrad of this shape runs on the halo-resident kernel (the one that takes pre-split operands)."""
+        return bool(self.conv_halo and self.lib.sgg_conv2d_nhwc_wgrad_resident(B, Ho, Wo, cin, cout, k, k, stride, self.conv_precision))
+
+    def conv_wgrad(self, x, dy, dw, stride, amax_x=None, amax_dy=None, ln=None, x_s16=False, dy_s16=False):
+        """ln: as conv_fwd (x = pre-LayerNorm output of the producing layer; halo-resident wgrad kernel only).
+        x_s16 / dy_s16: the operand is a pre-split tensor of ln_elu_fwd / ln_elu_bwd (out_s16=True)."""
         self._dev(x, dy, dw)
         ln_s, ln_g, ln_b = ln if ln is not None else (None, None, None)
         self._dev(ln_s, ln_g, ln_b)
@@ -424,7 +436,7 @@ class HipKernels:
             sym, nb = "conv_c3_wgrad(call: kernel + slab reduce)", 4.0 * (x.numel() + dy.numel())      # conv1_1: HBM-bound
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad(
             _p(x), _p(dy), _p(dw), *d, self.conv_precision, 0 if self.conv_halo else 1, _p(amax_x), _p(amax_dy), _p(ln_s), _p(ln_g), _p(ln_b),
-            _p(ws), ws.numel(), self._stream()), nb),
+            int(bool(x_s16)) | (int(bool(dy_s16)) << 1), _p(ws), ws.numel(), self._stream()), nb),
             "sgg_conv2d_nhwc_wgrad")
 
     @staticmethod
@@ -436,9 +448,11 @@ class HipKernels:
         assert 0 <= y0 and 0 <= x0 and y0 + hv <= H and x0 + wv <= W, (region, H, W)
         return (W, y0, x0, hv, wv)
 
-    def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None, tile_stats=None, region=None):
+    def ln_elu_fwd(self, y, gamma, beta, a, stats, amax_out=None, tile_stats=None, region=None, out_s16=False):
         """tile_stats [B, n, 4]: per-tile (count, mean, M2, max dev) written by conv_fwd's epilogue (skips the statistics pass).
-        region (y0, x0, Hv, Wv): LayerNorm over that window of every sample only; `a` is written as zeros outside it."""
+        region (y0, x0, Hv, Wv): LayerNorm over that window of every sample only; `a` is written as zeros outside it.
+        out_s16: `a` is written pre-split for the consuming convolutions (include/sgg_hip.h, out_format 1); amax_out (zeroed by the
+        caller) then receives an upper bound of max|a|."""
         self._dev(y, gamma, beta, a, stats, amax_out, tile_stats)
         B, H, W, C = y.shape
         assert region is None or tile_stats is None
@@ -449,7 +463,7 @@ class HipKernels:
         nb = 4.0 * y.numel() * (2 if nts else 3)
         self._check(self._timed("ln_elu_fwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_fwd(
             _p(y), _p(gamma), _p(beta), _p(a), _p(stats), _p(amax_out), _p(tile_stats), nts, B, H * W, C,
-            *self._region(region, H, W), _p(ws), ws.numel(), self._stream()), nb), "sgg_layernorm_hwc_elu_fwd")
+            *self._region(region, H, W), int(bool(out_s16)), _p(ws), ws.numel(), self._stream()), nb), "sgg_layernorm_hwc_elu_fwd")
 
     def ln_finalize(self, tile_stats, gamma, beta, stats, amax_out, hw):
         """Statistics only: stats [B,2] = (mean, rstd) from the conv epilogue's tile partials [B,n,4]; amax_out (1 word, may be None)
@@ -498,20 +512,26 @@ class HipKernels:
         self._check(self.lib.sgg_layernorm_hwc_bwd_finalize(ctypes.addressof(descs), len(descs), self._stream()),
                     "sgg_layernorm_hwc_bwd_finalize")
 
-    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None, ws=None):
+    def ln_elu_bwd(self, y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out=None, region=None, ws=None, out_s16=False,
+                   pq=None):
         """dgamma = dbeta = None with a workspace `ws` of the layer's own: the parameter-gradient reductions are deferred to
-        ln_bwd_finalize."""
+        ln_bwd_finalize.  out_s16: dy is written pre-split (amax_out receives an upper bound of max|dy|); pq: two ZEROED words for
+        the maxima that bound is made of (default: a pair zeroed here - one more launch)."""
         self._dev(y, da, gamma, beta, stats, dy, dgamma, dbeta, dbias_prev, amax_out, ws)
         B, H, W, C = y.shape
         need = self.lib.sgg_layernorm_hwc_elu_workspace_bytes(B, H * W, C)
         assert (dgamma is None) == (dbeta is None) and (dgamma is not None or ws is not None)
         if ws is None:
             ws = self.workspace(need)
+        if out_s16 and pq is None:
+            pq = torch.zeros(2, dtype=torch.float32, device=y.device)
+        self._dev(pq)
         assert ws.numel() * ws.element_size() >= need
         # bytes: the reduction reads y and da, the apply pass reads them again and writes dy
         self._check(self._timed("ln_elu_bwd(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_bwd(
             _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dgamma), _p(dbeta), _p(dbias_prev), _p(amax_out), B, H * W, C,
-            *self._region(region, H, W), _p(ws), ws.numel() * ws.element_size(), self._stream()), 4.0 * y.numel() * 5), "sgg_layernorm_hwc_elu_bwd")
+            *self._region(region, H, W), int(bool(out_s16)), _p(pq), _p(ws), ws.numel() * ws.element_size(), self._stream()), 4.0 * y.numel() * 5),
+            "sgg_layernorm_hwc_elu_bwd")
 
     # -- heads -----------------------------------------------------------------------------------------
     def spatial_mean_fwd(self, ctx, out_c, out_h):

@@ -141,6 +141,8 @@ class Trunk:
         # f16x3 mode: device words with max|tensor| of every conv operand (rows: activations a_j, gradients dy_j,
         # weights w_j), maintained by the producing kernels, so operands can be scaled into fp16 range without a host sync
         self.amax = torch.zeros((3, 16), device=dev, dtype=torch.float32)
+        # pre-split dy (LayerNorm backward): per layer the two maxima its bound is made of (zeroed with one fill per backward)
+        self.pq = torch.zeros((16, 2), device=dev, dtype=torch.float32)
         # LayerNorm backward: the parameter-gradient reductions of all layers in ONE launch at the end of the encoder backward
         # (K.ln_bwd_finalize), from per-layer workspaces that keep the partial sums until then
         self._ln_fin = None
@@ -218,8 +220,29 @@ class Trunk:
                 pays_fwd = True
             if lay["i"] in getattr(K, "ln_fusion_force_bwd", ()):
                 pays_bwd = True
+            if lay["i"] in getattr(K, "ln_fusion_skip_bwd", ()):  # (A/B option: keep the apply pass in passes a backward follows)
+                pays_bwd = False
             lay["fuse_ln"] = fwd_ok and pays_fwd
             lay["fuse_ln_bwd"] = both_ok and pays_bwd
+
+    def _plan_s16(self):
+        """lay["a_s16"] / lay["dy_s16"]: this layer's activation a_j = ELU(LN(y_j)) / the gradient dy_j its LayerNorm backward produces
+        is written PRE-SPLIT (two fp16 pieces per value in the f32 tensor's bytes: csrc/split16.h) by the LayerNorm kernel, so that the
+        convolutions that consume it stage it without splitting it again.  Needs the fp16 modes (per-tensor scale) and every consumer on
+        a resident kernel: a_j feeds conv_{j+1}'s forward and filter gradient, dy_j feeds conv_j's dgrad and filter gradient."""
+        K = self.K
+        on = bool(getattr(K, "presplit", False)) and getattr(K, "conv_precision", 0) in (1, 2) and hasattr(K, "wgrad_resident")
+        n = len(self.layers)
+        for j, lay in enumerate(self.layers):
+            lay["a_s16"] = lay["dy_s16"] = False
+            if not on or not lay["has_ln"]:
+                continue
+            B, ho, wo, cout = lay["out_shape"]
+            wg_ok = lambda l: K.wgrad_resident(B, l["out_shape"][1], l["out_shape"][2], l["cin"], l["cout"], l["k"], l["s"])
+            if j + 1 < n:
+                nxt = self.layers[j + 1]
+                lay["a_s16"] = nxt["ws_fwd"] is not None and nxt["ws_layout"] in (1, 2, 3, 4) and wg_ok(nxt)
+            lay["dy_s16"] = lay["cin"] != 3 and lay["ws_bwd"] is not None and lay["ws_layout_bwd"] in (1, 2, 3, 4) and wg_ok(lay)
 
     def refresh_weights(self):
         """Re-derive the operand formats of the convolution kernels after the parameters changed (Adam step / state-dict load):
@@ -249,6 +272,7 @@ class Trunk:
                 if lay["cin"] != 3 and lay["ws_fwd"] is not None and K.conv_precision:
                     lay["ws_mode"] = K.conv_precision
             self._plan_ln_fusion()
+            self._plan_s16()
             return
         if self._f16():
             self.K.fill(self.amax[2], 0.0)
@@ -269,6 +293,7 @@ class Trunk:
                     self.K.split_weights(lay["w3"] if lay["ws_layout_bwd"] == 3 else lay["w"], lay["ws_bwd"], self._am(2, j), lay["ws_layout_bwd"])
                     lay["ws_mode"] = self.K.conv_precision
         self._plan_ln_fusion()
+        self._plan_s16()
 
     def forward(self, images, for_backward=True):
         """images [B,S,S,3] NHWC fp32, already standardised (train.py:172) -> downsampled as ctx [B, L, 512].
@@ -286,6 +311,7 @@ class Trunk:
             images = self.img_canvas
         self.images = images
         x = images
+        x_s16 = False           # x is a pre-split activation (written so by the previous layer's LayerNorm)
         ln_in = None            # (stats, gamma, beta) when x is a pre-LayerNorm tensor whose LN + ELU this layer applies itself
         if self._f16():
             K.fill(self.amax[0], 0.0)
@@ -296,12 +322,17 @@ class Trunk:
             if ln_in is not None:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1), self._am(2, j), ts,
                            lay["ws_layout"], ln=ln_in)
+            elif x_s16:
+                assert ws is not None
+                K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1), self._am(2, j), ts, lay["ws_layout"],
+                           x_s16=True)
             elif ws is not None or self._f16() or ts is not None:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j), ts,
                            lay["ws_layout"] if ws is not None else 0)
             else:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             ln_in = None
+            x_s16 = False
             if lay["has_ln"]:
                 if lay.get(fuse_key) and ts is not None:
                     # statistics only; the consumer normalises y while it stages its patches (forward and wgrad)
@@ -311,7 +342,12 @@ class Trunk:
                     lay["fused_now"] = True
                     continue
                 lay["fused_now"] = False
-                if lay["region"] is not None:
+                # (the consumer must exist in the precision in force: its pre-split weights are what x_s16 above asserts)
+                s16 = bool(lay.get("a_s16")) and j + 1 < len(self.layers) and self.layers[j + 1].get("ws_mode") == getattr(K, "conv_precision", 0)
+                lay["a_s16_now"] = s16
+                if s16:
+                    K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], self._am(0, j), ts, region=lay["region"], out_s16=True)
+                elif lay["region"] is not None:
                     K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"], *([self._am(0, j), None] if self._f16() else []),
                                  region=lay["region"])
                 elif self._f16() or ts is not None:
@@ -319,6 +355,7 @@ class Trunk:
                 else:
                     K.ln_elu_fwd(lay["y"], lay["gamma"], lay["beta"], lay["a"], lay["stats"])
                 x = lay["a"]
+                x_s16 = s16
             else:
                 x = lay["y"]
         return x.view(self.B, self.L, FEAT_C)
@@ -345,18 +382,25 @@ class Trunk:
         if f16:
             K.fill(self.amax[1], 0.0)
             K.absmax(dy, self._am(1, n - 1))
+            if any(l.get("dy_s16") for l in self.layers):
+                K.fill(self.pq, 0.0)
         cur = -1                                   # dY buffer holding dy (-1: the caller's dctx)
+        dy_s16 = False                             # dy is pre-split (written so by the LayerNorm backward of this layer)
         for j in range(n - 1, -1, -1):
             lay = self.layers[j]
             prv = self.layers[j - 1] if j else None
 
-            def wgrad(dy=dy, j=j, lay=lay, prv=prv):
+            def wgrad(dy=dy, j=j, lay=lay, prv=prv, dy_s16=dy_s16):
                 if prv is not None and prv.get("fused_now"):
                     # the input activation was never written: the wgrad kernel applies LayerNorm + ELU to the producing layer's y
-                    K.conv_wgrad(prv["y"], dy, lay["gw"], lay["s"], self._am(0, j - 1), self._am(1, j), ln=(prv["stats"], prv["gamma"], prv["beta"]))
+                    K.conv_wgrad(prv["y"], dy, lay["gw"], lay["s"], self._am(0, j - 1), self._am(1, j), ln=(prv["stats"], prv["gamma"], prv["beta"]),
+                                 **({"dy_s16": True} if dy_s16 else {}))
                 else:
                     x_in = self.images if j == 0 else prv["a"]
-                    if f16:
+                    x_s16 = bool(j and prv.get("a_s16_now"))
+                    if x_s16 or dy_s16:
+                        K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j), x_s16=x_s16, dy_s16=dy_s16)
+                    elif f16:
                         K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
                     else:
                         K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
@@ -383,11 +427,18 @@ class Trunk:
                 reader_done[nxt] = None
             dYp = dybufs[nxt][:numel].view(prev["out_shape"])
             ws = lay["ws_bwd"] if (lay["ws_bwd"] is not None and lay.get("ws_mode") == getattr(K, "conv_precision", 0)) else None
-            if ws is not None or f16:
+            if dy_s16:
+                assert ws is not None
+                K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"], dy_s16=True)
+            elif ws is not None or f16:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"] if ws is not None else 0)
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])
-            if self._ln_fin is not None:
+            nxt_s16 = bool(prev.get("dy_s16")) and prev.get("ws_mode") == getattr(K, "conv_precision", 0) and self._ln_fin is not None
+            if nxt_s16:
+                K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, None, None, None, self._am(1, j - 1),
+                             region=prev["region"], ws=prev["ln_ws"], out_s16=True, pq=self.pq[j - 1])
+            elif self._ln_fin is not None:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, None, None, None, self._am(1, j - 1) if f16 else None,
                              region=prev["region"], ws=prev["ln_ws"])
             elif prev["region"] is not None:
@@ -398,7 +449,7 @@ class Trunk:
                              self._am(1, j - 1))
             else:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, prev["ggamma"], prev["gbeta"], prev["gb"])
-            dy, cur = dYp, nxt
+            dy, cur, dy_s16 = dYp, nxt, nxt_s16
         if self._ln_fin is not None:
             K.ln_bwd_finalize(self._ln_fin)       # dgamma, dbeta and the conv bias gradients of all eleven LayerNorms
         if side is not None:

@@ -23,13 +23,13 @@ case $STEP in
     head -c 300 $O/bench_config3.json; echo; head -c 300 $O/bench_config4.json ;;
   stats)
     cd /tmp && export TMPDIR=/tmp
-    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 --f32-steps 0 --ci10-steps 0 --two-stream-steps 0 > $O/bench_under_rocprof.json 2> $O/stats.err
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 $R/bench.py --steps 5 --warmup 2 --single-stream --serial-steps 0 --other-configs 0 --cpu-rows 0 --f32-steps 0 --ci10-steps 0 > $O/bench_under_rocprof.json 2> $O/stats.err
     rm -f $O/stats/k_kernel_trace.csv
     head -30 $O/stats/k_kernel_stats.csv ;;
   pmc)
     cd /tmp && export TMPDIR=/tmp
-    timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-rows 0 --f32-steps 0 --ci10-steps 0 --two-stream-steps 0 --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-    timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-rows 0 --f32-steps 0 --ci10-steps 0 --two-stream-steps 0 --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
+    timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --single-stream --serial-steps 0 --other-configs 0 --cpu-rows 0 --f32-steps 0 --ci10-steps 0 --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+    timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --single-stream --serial-steps 0 --other-configs 0 --cpu-rows 0 --f32-steps 0 --ci10-steps 0 --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
     rm -f $O/pmc_fetch/f_kernel_trace.csv $O/pmc_write/w_kernel_trace.csv
     ls -la $O/pmc_fetch $O/pmc_write ;;
 esac
