@@ -576,22 +576,34 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restric
 #pragma unroll
   for (int k = 0; k < 27; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w + k * COUT + sub * 4);
   const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + sub * 4);
+  // the patch of the NEXT tile is fetched into registers while this tile is computed (two pixels per thread): with the loads issued
+  // between the two barriers their whole latency was exposed once per tile (two resident workgroups per CU cannot hide it)
+  f32x4 pv[2];
+  auto load_patch = [&](int tile_) __attribute__((always_inline)) {
+    const int tx_ = tile_ % tiles_x, t2_ = tile_ / tiles_x;
+    const int ty_ = t2_ % tiles_y, b_ = t2_ / tiles_y;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx / 34, c = idx % 34;
+      const int yy = ty_ * 8 - pt + r, xx = tx_ * 32 - pl + c;
+      pv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tile_ < ntiles && idx < 10 * 34 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+        const float* px = x + ((size_t)(b_ * H + yy) * W + xx) * 3;
+        pv[k][0] = px[0]; pv[k][1] = px[1]; pv[k][2] = px[2];
+      }
+    }
+  };
+  load_patch(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int tx = tile % tiles_x, t2 = tile / tiles_x;
   const int ty = t2 % tiles_y, b = t2 / tiles_y;
   const int y0 = ty * 8, x0 = tx * 32;
   __syncthreads();            // the previous tile's patch / reduction scratch are free
-  for (int idx = tid; idx < 10 * 34; idx += 256) {
-    const int r = idx / 34, c = idx % 34;
-    const int yy = y0 - pt + r, xx = x0 - pl + c;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-      const float* px = x + ((size_t)(b * H + yy) * W + xx) * 3;
-      v[0] = px[0]; v[1] = px[1]; v[2] = px[2];
-    }
-    patch[idx] = v;
-  }
+  patch[tid] = pv[0];
+  if (tid + 256 < 10 * 34) patch[tid + 256] = pv[1];
   __syncthreads();
+  load_patch(tile + gridDim.x);
 
   f32x4 rows[3][3];
 #pragma unroll

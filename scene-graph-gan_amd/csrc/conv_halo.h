@@ -80,9 +80,10 @@ struct WgradDmaPlan {
   int spw;              // partial slabs a workgroup writes
   int pairs, pairs_n;   // channel tiles; Cout tiles
   int nsplit, stages, nslabs;
+  int geo, R, pc, xslots; // geo 1: row bands as WgradHaloPlan (grids that 8x8 blocks do not tile; 64 x 64 tiles)
   size_t ws_bytes;
 };
-// returns 1 and fills the plan if the shape is served (H, W = the dy grid, divisible by 8; 3x3 stride 1 or 5x5 stride 2; channels % 64 == 0)
+// returns 1 and fills the plan if the shape is served (H, W = the dy grid: divisible by 8, or row bands of up to 112 pixels; 3x3 stride 1 or 5x5 stride 2; channels % 64 == 0)
 int sgg_wgrad_dma_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradDmaPlan* pl);
 // x, dy: pre-split ("S16") tensors; writes pl.nslabs partial dW slabs [slab][taps][Cin][Cout] (unscaled f32) into `slabs`
 void sgg_wgrad_dma_launch(const void* x, const void* dy, float* slabs, int B, int H, int W, int Cin, int Cout, int stride, int pad_t,

@@ -494,30 +494,43 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int tx = t % tiles_x, t2 = t / tiles_x;
-    const int ty = t2 % tiles_y, b = t2 / tiles_y;
-    const int y0 = ty * 8, x0 = tx * 32;
-    __syncthreads();
-    for (int idx = tid; idx < 10 * 34; idx += 256) {
+  // the NEXT tile's patch pixels and dy vectors are fetched into registers while this tile is computed (conv_c3_fwd_kernel): the
+  // loads sat between the two barriers of a tile, their latency exposed once per tile
+  f32x4 pv[2], dvn[8];
+  auto load_tile = [&](int t_) __attribute__((always_inline)) {
+    const int tx_ = t_ % tiles_x, t2_ = t_ / tiles_x;
+    const int ty_ = t2_ % tiles_y, b_ = t2_ / tiles_y;
+    const int y0_ = ty_ * 8, x0_ = tx_ * 32;
+    const bool live = t_ < t_end;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + 256 * k;
       const int r = idx / 34, c = idx % 34;
-      const int yy = y0 - pt + r, xx = x0 - pl + c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-        const float* px = x + ((size_t)(b * H + yy) * W + xx) * 3;
-        v[0] = px[0]; v[1] = px[1]; v[2] = px[2];
+      const int yy = y0_ - pt + r, xx = x0_ - pl + c;
+      pv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (live && idx < 10 * 34 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+        const float* px = x + ((size_t)(b_ * H + yy) * W + xx) * 3;
+        pv[k][0] = px[0]; pv[k][1] = px[1]; pv[k][2] = px[2];
       }
-      patch[idx] = v;
     }
     // this thread's 8 dy vectors (zeros outside the image: they contribute nothing)
-    f32x4 dv[8];
-    const bool col_ok = x0 + col < W;
+    const bool col_ok = live && x0_ + col < W;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      dv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (col_ok && y0 + r < H) dv[r] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(b * H + y0 + r) * W + x0 + col) * COUT + sub * 4);
+      dvn[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col_ok && y0_ + r < H) dvn[r] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(b_ * H + y0_ + r) * W + x0_ + col) * COUT + sub * 4);
     }
+  };
+  load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
+    patch[tid] = pv[0];
+    if (tid + 256 < 10 * 34) patch[tid + 256] = pv[1];
+    f32x4 dv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dv[r] = dvn[r];
+    __syncthreads();
+    load_tile(t + 1);
     f32x4 rows[3][3];
 #pragma unroll
     for (int r = 0; r < 2; ++r)

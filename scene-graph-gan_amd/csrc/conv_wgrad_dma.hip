@@ -211,13 +211,194 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradDmaParams p
     }
 }
 
+// ---- row bands (grids that 8x8 blocks do not tile: 28x28, 14x14 - conv3_5, `downsampled`) -----------------------------------------
+// Geometry of conv_wgrad_halo3_kernel's GEO 1: a block is R full-width rows of one image (R * W <= 112 pixels = seven 16-pixel MFMA
+// steps), the patch is (R + 2) rows of pitch W + 1 - slot 0 of a row is the zero column that serves as right halo of the row above
+// and left halo of this one.  64 x 64 channel tiles, the eight waves = 2 x 2 tiles x 2 groups of k-steps (4 + 3); 147 KB of LDS
+// (two buffers of 176 patch slots + 112 dy pixels, 2 groups x 2 planes each).
+struct WgradDmaRbParams {
+  WgradDmaParams d;
+  int R, pc, xslots, npx;
+  unsigned magic_w, magic_pc;       // ceil(2^32 / W), ceil(2^32 / pc)
+};
+#define WDR_XSLOTS 176
+#define WDR_XSUB (WDR_XSLOTS * 64)
+#define WDR_XPLANE (2 * WDR_XSUB)
+#define WDR_DPX 112
+#define WDR_DSUB (WDR_DPX * 64)
+#define WDR_DPLANE (2 * WDR_DSUB)
+#define WDR_BUF (2 * WDR_XPLANE + 2 * WDR_DPLANE)
+
+template <int NKH, int NKW>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_dma_rb_kernel(WgradDmaRbParams pr) {
+  const WgradDmaParams& p = pr.d;
+  constexpr int NTAP = NKH * NKW;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * WDR_BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, pair = blockIdx.y;
+  const int c0 = (pair / p.pairs_n) * 64, n0 = (pair % p.pairs_n) * 64;
+  const int ci_t = (wave >> 1) & 1, co_t = wave & 1, kg = wave >> 2;
+  const int ks_begin = kg ? 4 : 0, ks_end = kg ? 7 : 4;          // k-steps of this wave
+  const wd_v4i rs_x = wd_rsrc(p.x, p.x_bytes), rs_dy = wd_rsrc(p.dy, p.dy_bytes);
+  const int ea = scale_exp_from_amax(*p.amax_x), eb = scale_exp_from_amax(*p.amax_dy);
+
+  // ---- DMA plan: x instructions q = wave and wave + 8 (11 of them cover the 176 slots), each for the four (group, plane) images;
+  // dy instruction q = wave (7 cover the 112 pixels), for the two groups x two planes -----------------------------------------------
+  const int piece = lane & 3;
+  unsigned xrel[2];
+  int xmeta[2];                    // bits 0..7 patch row, 8 zero column, 9 valid
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int slot = 16 * (wave + 8 * k) + (lane >> 2);
+    const int ry = (int)__umulhi((unsigned)slot, pr.magic_pc), rx = slot - ry * pr.pc;
+    xrel[k] = (unsigned)(((ry * p.sxy * p.Wx + rx * p.sxy) * p.C) * 4 + piece * 16);
+    xmeta[k] = ry | ((rx == 0) << 8) | ((int)(slot < pr.xslots && wave + 8 * k < 11) << 9);
+  }
+  const int dpx = 16 * wave + (lane >> 2);
+  const unsigned drel = (unsigned)((dpx * p.N) * 4 + piece * 16);
+
+  const int blk_begin = split * p.stages;
+  auto issue = [&](int s, unsigned char* buf) __attribute__((always_inline)) {
+    const int beta = blk_begin + s;
+    const bool dead = (s >= p.stages) | (beta >= p.nblk);
+    const int b = beta / p.bh, band = beta - b * p.bh;
+    const int r0 = band * pr.R;
+    const int rows_left = p.H - r0;
+    const int npx_valid = (rows_left < pr.R ? rows_left : pr.R) * p.W;
+    const unsigned xbase = (unsigned)((((b * p.Hx + (r0 - 1) * p.sxy + p.cy) * p.Wx - p.sxy + p.cx) * p.C + c0) * 4);
+    const unsigned dbase = (unsigned)((((b * p.H + r0) * p.W) * p.N + n0) * 4);
+    const unsigned la = wd_lds_addr(buf);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (wave + 8 * k < 11) {        // (uniform)
+        const int ry = xmeta[k] & 255;
+        const bool bad = dead | !((xmeta[k] >> 9) & 1) | ((xmeta[k] >> 8) & 1) | ((ry == 0) & (r0 == 0)) | (ry > rows_left);
+        const unsigned xo = bad ? SGG_OOB : xbase + xrel[k];
+        const unsigned xd = la + (wave + 8 * k) * 1024;
+        wd_dma16(rs_x, xd, xo, 0);
+        wd_dma16(rs_x, xd + WDR_XSUB, xo, 128);
+        wd_dma16(rs_x, xd + WDR_XPLANE, xo, 64);
+        wd_dma16(rs_x, xd + WDR_XPLANE + WDR_XSUB, xo, 192);
+      }
+    }
+    if (wave < 7) {
+      const unsigned dof = (dead | (dpx >= npx_valid)) ? SGG_OOB : dbase + drel;
+      const unsigned dd = la + 2 * WDR_XPLANE + wave * 1024;
+      wd_dma16(rs_dy, dd, dof, 0);
+      wd_dma16(rs_dy, dd + WDR_DSUB, dof, 128);
+      wd_dma16(rs_dy, dd + WDR_DPLANE, dof, 64);
+      wd_dma16(rs_dy, dd + WDR_DPLANE + WDR_DSUB, dof, 192);
+    }
+  };
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, pch = lane & 3;
+  const int choff = ((g & 1) * 2 + (pch >> 1)) * 16 + (pch & 1) * 8;
+  const int a_off = ci_t * WDR_XSUB + ((p.a0y + 1) * pr.pc + p.a0x + 1) * 64 + choff;
+  const int b_off = 2 * WDR_XPLANE + co_t * WDR_DSUB + ((g >> 1) * 8 + q) * 64 + choff;
+  auto rb_slot = [&](int pid) __attribute__((always_inline)) {      // byte offset of pixel pid's patch slot (past the band: clamped, dy is zero there)
+    pid = pid < pr.npx ? pid : pr.npx - 1;
+    const int row = (int)__umulhi((unsigned)pid, pr.magic_w);
+    return (row * pr.pc + (pid - row * p.W)) * 64;
+  };
+
+  f32x16 acc[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto compute = [&](const unsigned char* buf) __attribute__((always_inline)) {
+    const unsigned char* a_base = buf + a_off;
+    const unsigned char* b_base = buf + b_off;
+    const int pc64 = pr.pc * 64;
+    // (not unrolled over the k-steps: the per-step patch addresses are run-time values; unrolled they are hoisted and spilled)
+#pragma unroll 1
+    for (int ksi = ks_begin; ksi < ks_end; ++ksi) {
+      u32x4 b[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        const wd_u32x2 lo = wd_tr16(b_base + ksi * 1024 + pp * WDR_DPLANE);
+        const wd_u32x2 hi = wd_tr16(b_base + ksi * 1024 + 256 + pp * WDR_DPLANE);
+        b[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+      const int pid = 16 * ksi + 8 * (g >> 1) + q;
+      const unsigned char* alo = a_base + rb_slot(pid);
+      const unsigned char* ahi = a_base + rb_slot(pid + 4);
+#pragma unroll
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const int kh = tap / NKW, kw = tap % NKW;
+        u32x4 a[2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const wd_u32x2 lo = wd_tr16(alo + kh * pc64 + kw * 64 + pp * WDR_XPLANE);
+          const wd_u32x2 hi = wd_tr16(ahi + kh * pc64 + kw * 64 + pp * WDR_XPLANE);
+          a[pp] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        f32x16 d = acc[tap];
+        d = mfma16<true>(a[1], b[0], d);
+        d = mfma16<true>(a[0], b[1], d);
+        d = mfma16<true>(a[0], b[0], d);
+        acc[tap] = d;
+      }
+    }
+  };
+
+  issue(0, lds);
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < p.stages; ++s) {
+    unsigned char* cur = lds + (s & 1) * WDR_BUF;
+    issue(s + 1, lds + ((s + 1) & 1) * WDR_BUF);
+    __builtin_amdgcn_sched_barrier(0);
+    SGG_PRIO_HI();
+    compute(cur);
+    SGG_PRIO_LO();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+  }
+
+  float* o = p.slabs + (size_t)(split * 2 + kg) * p.taps_total * p.C * p.N;
+#pragma unroll
+  for (int tap = 0; tap < NTAP; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = c0 + ci_t * 32 + acc_row(r, lane);
+      const int co = n0 + co_t * 32 + acc_col(lane);
+      const int ktap = (p.kh0 + p.kstep * (tap / NKW)) * p.KWt + p.kw0 + p.kstep * (tap % NKW);
+      o[((size_t)ktap * p.C + ci) * p.N + co] = ldexpf(ldexpf(acc[tap][r], -ea), -eb);
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------
 // H, W: the dy grid (both divisible by 8); 3x3 stride 1 or 5x5 stride 2 with an even x grid; Cin, Cout % 64 == 0.
 int sgg_wgrad_dma_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, WgradDmaPlan* pl) {
   const bool k3 = KH == 3 && KW == 3 && stride == 1, k5 = KH == 5 && KW == 5 && stride == 2;
-  if (!((k3 || k5) && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cin % 64 == 0 && Cout % 64 == 0)) return 0;
+  if (!((k3 || k5) && B > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 64 == 0)) return 0;
   if ((size_t)B * H * W * stride * stride * Cin * sizeof(float) >= 0x80000000ull || (size_t)B * H * W * Cout * sizeof(float) >= 0x80000000ull)
     return 0;
+  pl->geo = 0; pl->R = 8; pl->pc = 12; pl->xslots = 120;
+  if (H % 8 != 0 || W % 8 != 0) {
+    // row bands (conv_wgrad_halo.hip: sgg_wgrad_halo_plan): R full-width rows, R * W <= 112 pixels, (R + 2) * (W + 1) + 1 <= 176 slots
+    int R = 112 / W;
+    if (R > H) R = H;
+    while (R > 0 && (R + 2) * (W + 1) + 1 > 176) --R;
+    if (R < 1) return 0;
+    pl->geo = 1; pl->R = R; pl->pc = W + 1; pl->xslots = (R + 2) * (W + 1) + 1;
+    pl->nt = 2; pl->spw = 2;
+    pl->pairs_n = Cout / 64;
+    pl->pairs = (Cin / 64) * pl->pairs_n;
+    const int nb = B * ((H + R - 1) / R);
+    int nsr = 256 / pl->pairs;
+    if (nsr > nb / 4) nsr = nb / 4;
+    if (nsr < 1) nsr = 1;
+    pl->stages = (nb + nsr - 1) / nsr;
+    pl->nsplit = (nb + pl->stages - 1) / pl->stages;
+    pl->nslabs = pl->nsplit * pl->spw;
+    pl->ws_bytes = (size_t)pl->nslabs * KH * KW * Cin * Cout * sizeof(float);
+    return 1;
+  }
   pl->nt = Cout % 128 == 0 ? 4 : 2;
   pl->spw = pl->nt == 4 ? 1 : 2;
   pl->pairs_n = Cout / (32 * pl->nt);
@@ -236,6 +417,16 @@ int sgg_wgrad_dma_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, i
 template <int NKH, int NKW>
 static void wgrad_dma_launch_class(const WgradDmaParams& p, const WgradDmaPlan& pl, hipStream_t st) {
   const dim3 grid(pl.nsplit, pl.pairs);
+  if (pl.geo == 1) {
+    WgradDmaRbParams pr;
+    pr.d = p;
+    pr.d.bh = (p.H + pl.R - 1) / pl.R; pr.d.bw = 1; pr.d.nblk = p.B * pr.d.bh;
+    pr.R = pl.R; pr.pc = pl.pc; pr.xslots = pl.xslots; pr.npx = pl.R * p.W;
+    pr.magic_w = (unsigned)((0x100000000ull + p.W - 1) / p.W);
+    pr.magic_pc = (unsigned)((0x100000000ull + pl.pc - 1) / pl.pc);
+    hipLaunchKernelGGL((conv_wgrad_dma_rb_kernel<NKH, NKW>), grid, dim3(512), 0, st, pr);
+    return;
+  }
   if (pl.nt == 4) hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, NKH, NKW>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, NKH, NKW>), grid, dim3(512), 0, st, p);
 }

@@ -180,7 +180,19 @@ class Trunk:
             return False
         if prev["i"] in getattr(K, "ln_fusion_skip", ()):
             return False
+        if mode == 1 and self._pc_presplit(lay):
+            return False
         return mode == 2 or any(ln_fusion_pays(prev["out_shape"], lay["cout"]))
+
+    def _pc_presplit(self, lay):
+        """With pre-split activations a consumer on the producer / consumer 3x3 kernel (128-column layers) stages its patch by
+        LDS-DMA and its filter gradient runs on the LDS-DMA kernel; an LN prologue would put both back on the register-staging
+        kernels.  Measured with the prologue kept for these consumers: 45.29 / 45.20 against 45.09 / 45.16 ms per step without
+        (profiles/r04_ln_fusion_plan_presplit_ab.log) - and the plain producer / consumer kernel is the faster kernel (0.50 of the
+        matrix peak against 0.43): those LayerNorms keep their apply pass."""
+        K = self.K
+        return (bool(getattr(K, "presplit", False)) and getattr(K, "conv_precision", 0) == 2 and hasattr(K, "conv_wsplit_layout") and
+                K.conv_wsplit_layout(lay["k"], lay["s"], lay["hin"], lay["win"], lay["cin"], lay["cout"]) == 4)
 
     def _f16(self):
         return getattr(self.K, "conv_precision", 0) in (1, 2)      # fp16 pieces: per-tensor scaling from the amax words
@@ -214,6 +226,8 @@ class Trunk:
                 lay["fuse_ln"] = lay["fuse_ln_bwd"] = both_ok
                 continue
             pays_fwd, pays_bwd = ln_fusion_pays(lay["out_shape"], nxt["cout"])
+            if self._pc_presplit(nxt):
+                pays_fwd = pays_bwd = False
             if lay["i"] in getattr(K, "ln_fusion_skip", ()):      # (A/B option ln_fusion_skip of sgg_amd/lib.py)
                 pays_fwd = pays_bwd = False
             if lay["i"] in getattr(K, "ln_fusion_force", ()):     # (A/B option ln_fusion_force)

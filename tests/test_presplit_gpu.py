@@ -188,10 +188,15 @@ def test_row_band_filter_gradient_with_presplit_operands_is_bit_equal(mode2, cas
     x, dy = rnd((B, H, W, Ci), 5), rnd((B, Ho, Wo, Co), 6)
     bx, bdy = 1.3 * float(x.abs().max()), 5.0 * float(dy.abs().max())
     am_x, am_dy = torch.tensor([bx], device="cuda"), torch.tensor([bdy], device="cuda")
-    dw = [torch.full((k, k, Ci, Co), float("nan"), device="cuda") for _ in range(2)]
+    dw = [torch.full((k, k, Ci, Co), float("nan"), device="cuda") for _ in range(4)]
+    x16, dy16 = to_s16(x, bx).cuda(), to_s16(dy, bdy).cuda()
     hip.conv_wgrad(x.cuda(), dy.cuda(), dw[0], s, am_x, am_dy)
-    hip.conv_wgrad(to_s16(x, bx).cuda(), to_s16(dy, bdy).cuda(), dw[1], s, am_x, am_dy, x_s16=True, dy_s16=True)
-    assert torch.isfinite(dw[0]).all() and torch.equal(dw[0], dw[1]), "max |d| = %.3e" % float((dw[0] - dw[1]).abs().max())
+    hip.conv_wgrad(x16, dy.cuda(), dw[1], s, am_x, am_dy, x_s16=True)                    # register-staged row-band kernel: bit-equal
+    hip.conv_wgrad(x.cuda(), dy16, dw[2], s, am_x, am_dy, dy_s16=True)
+    hip.conv_wgrad(x16, dy16, dw[3], s, am_x, am_dy, x_s16=True, dy_s16=True)            # LDS-DMA row-band kernel: another summation order
+    assert torch.isfinite(dw[0]).all() and torch.equal(dw[0], dw[1]) and torch.equal(dw[0], dw[2])
+    assert torch.isfinite(dw[3]).all()
+    assert float((dw[0] - dw[3]).abs().max()) <= 5e-6 * float(dw[0].abs().max()), "max |d| = %.3e" % float((dw[0] - dw[3]).abs().max())
 
 
 def test_presplit_operands_are_rejected_where_no_kernel_takes_them(hip):
@@ -222,6 +227,10 @@ DMA_CASES = [
     (1, 8, 16, 128, 64, 3, 1),
     (3, 32, 32, 128, 128, 5, 2),     # the four stride-2 parity classes (conv2_5)
     (2, 16, 48, 64, 128, 5, 2),
+    (3, 56, 56, 64, 128, 5, 2),      # row bands: 28 x 28 grid in 4-row bands (conv3_5)
+    (2, 28, 28, 128, 64, 5, 2),      # 14 x 14 grid in 8-row bands, the second band ragged (`downsampled`)
+    (2, 20, 20, 64, 64, 3, 1),       # 20 x 20: bands of 5 rows
+    (1, 9, 9, 64, 128, 3, 1),        # one band per image
 ]
 
 

@@ -59,6 +59,25 @@ def test_forward_without_prologue_takes_the_pc_kernel():
     assert lay["ws_layout"] == 4
 
 
+def test_presplit_activations_keep_the_pc_kernel_and_drop_the_prologue_for_its_consumers():
+    """With pre-split activations (K.presplit) a 128-column consumer stages its patch by LDS-DMA on the producer / consumer kernel:
+    its producer's LayerNorm keeps the apply pass (trunk._pc_presplit), so the forward asks for layout 4 as well."""
+    K = _K()
+    K.presplit = True
+    prev = _lay(5, 64, 128, 3, 1, 112, None)
+    lay = _lay(6, 128, 128, 3, 1, 112, prev)
+    t = _trunk(K)
+    assert t._pc_presplit(lay) and not t._ln_prologue_expected(lay)
+    t._query_layouts(lay)
+    assert lay["ws_layout"] == 4 and lay["ws_layout_bwd"] == 4
+    K.conv_precision = 3                                          # bf16 pieces: no pre-split tensors, the round-3 routing stands
+    t._query_layouts(lay)
+    assert lay["ws_layout"] == 1
+    lay64 = _lay(4, 64, 64, 3, 1, 112, _lay(3, 32, 64, 3, 1, 112, None))      # a 64-column consumer is not on that kernel
+    K.conv_precision = 2
+    assert not t._pc_presplit(lay64)
+
+
 def test_other_layers_are_untouched():
     K = _K()
     lay = _lay(3, 32, 64, 3, 1, 112, _lay(2, 32, 32, 5, 2, 224, None))      # conv2_1: 64 columns
