@@ -139,6 +139,9 @@ def conv_roofline(per, precision, dt):
             (dom.startswith("conv_s2_kernel") and len(targs) > 4 and targs[4] == "true"):
         r["kernel_note"] = ("this instantiation also applies the producing layer's LayerNorm + ELU while staging its patches (LN prologue: "
                             "that work replaces a separate HBM pass and is not counted in `achieved`); the plain instantiation is in kernel_tflops_extra_steps")
+    if dom.startswith("conv_halo3_pc_kernel") and len(targs) > 2 and targs[2] == "true":
+        r["kernel_note"] = ("producer / consumer 3x3 kernel on a pre-split source: weight fragments AND the activation patch are staged by "
+                            "LDS-DMA (buffer_load ... lds), the MFMA waves issue LDS reads, v_mfma_f32_16x16x32_f16 and stores only")
     if precision in (1, 2, 3, 4):
         # a register-only loop of v_mfma_f32_32x32x16_f16 on random operands sustains 1.56-1.71 PFLOP/s: the chip clocks down
         # under matrix load (2.46 PFLOP/s only with all-zero operands) -> / 3 products

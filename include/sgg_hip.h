@@ -119,7 +119,10 @@ int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw_hwio, int B
                           int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int algo,
                           const float* amax_x, const float* amax_dy, const float* ln_stats, const float* ln_gamma, const float* ln_beta,
                           int operand_format, void* workspace, size_t workspace_bytes, void* stream);
-/* 1 if the halo-resident filter-gradient kernel serves this shape with algo 0 (the kernel that takes pre-split operands) */
+/* 0: the per-tap kernels serve this shape; 1: the halo-resident kernel does with algo 0 (it takes pre-split operands and stages them
+ * through registers, without arithmetic); 2: as 1, and when BOTH operands are pre-split (operand_format 3, precision 2, no LN prologue)
+ * the LDS-DMA kernel runs instead: 64 x 128 / 64 x 64 channel tiles, both operands copied HBM -> LDS by `buffer_load ... lds`, no
+ * staging registers or arithmetic (csrc/conv_wgrad_dma.hip; channels % 64 == 0, 8-divisible grids or row bands of <= 112 pixels) */
 int sgg_conv2d_nhwc_wgrad_resident(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision);
 
 /* ---- tf.contrib.layers.layer_norm(activation_fn=tf.nn.elu) over (H,W,C) per sample ------------------------

@@ -29,13 +29,24 @@
 #include "conv_halo.h"
 #include <type_traits>
 
+// Timing-only ablations (wrong results by design; scripts/build_variant_one.sh): S2_ABL_NOSTAGE = no patch staging after the first
+// stage, S2_ABL_NOB = the weight fragments are loaded once, S2_ABL_NOEPI = no output stores / statistics, S2_ABL_NOA = the A
+// fragments are read once per stage (no LDS reads in the tap loop).
+#ifndef S2_ABL_NOSTAGE
+#define S2_ABL_NOSTAGE 0
+#endif
+#ifndef S2_ABL_NOB
+#define S2_ABL_NOB 0
+#endif
+#ifndef S2_ABL_NOEPI
+#define S2_ABL_NOEPI 0
+#endif
 #ifndef SGG_WIDE_STORE
 #define SGG_WIDE_STORE 1        // 16-byte output stores through an in-register quad transpose (sgg_common.h); 0: 4-byte stores
 #endif
 #define S2_BAND 224                   // positions per band in the 7-tile variant (what LayerNorm partials are defined on)
 #define S2_MAXSLOTS 496               // 2 buffers x 2 planes x 496 x 32 B + the row tables stay inside 64 KB of static LDS
 #define S2_ZSLOT (S2_MAXSLOTS - 1)    // never part of a patch: staged as zeros (out-of-range loads), read by edge lanes
-#define S2_PLB (S2_MAXSLOTS * 32)      // bytes of one plane of one patch buffer
 #define S2_NPASS 4                     // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256
 #define S2_BN 128
 #ifndef S2_SMALL_ITEMS
@@ -46,6 +57,9 @@
 // deterministic); 2 = both.  Measured 49.34 / 48.92 / 49.60 ms per G+D step (same box, two repetitions).
 #ifndef S2_KSPLIT_MODE
 #define S2_KSPLIT_MODE 1
+#endif
+#ifndef S2_DMA
+#define S2_DMA 1              // 0: a pre-split source is staged through registers (no arithmetic) like an f32 one
 #endif
 #ifndef S2_SWZ
 #define S2_SWZ(slot) (((slot) >> 3) & 1)      // which 16-B half of a slot holds channels 0..7
@@ -73,10 +87,16 @@ constexpr int cls_ntaps(int cls) { return (cls_qy(cls) ? 3 : 2) * (cls_qx(cls) ?
 // (band, n-tile) work items than the chip has CUs (`downsampled` at batch 64: 56 bands x 4 n-tiles).
 // ONE: single-piece mode (precision 1 / 4): one 16-bit plane, one MFMA per product.
 // LNP: LN prologue (forward): src is the producing layer's pre-LayerNorm output, normalised + ELU'd while the patch is staged.
-template <bool DGRAD, bool HALF, int MT, bool ONE = false, bool LNP = false>
+// DMAP: src is a PRE-SPLIT tensor (split16.h; HALF, two pieces, no prologue): the patch goes HBM -> LDS by LDS-DMA (inline assembly:
+// invisible to the compiler's wait-count pass, waited for by an explicit s_waitcnt at the end of the stage), issued at the stage's
+// FIRST tap into the buffer the workgroup left at the last barrier - no staging registers, loads, conversions or LDS writes.
+template <bool DGRAD, bool HALF, int MT, bool ONE = false, bool LNP = false, bool DMAP = false>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   static_assert(!LNP || (!DGRAD && !ONE), "the LN prologue exists for the forward of the two-piece modes");
+  static_assert(!DMAP || (HALF && !ONE && !LNP), "patch DMA: pre-split fp16 pieces, no prologue");
   constexpr int P = ONE ? 1 : 2;
+  // bytes of one plane of one patch buffer; DMAP: 512 slots, because the 32nd DMA instruction of a plane covers slots 480 .. 511
+  constexpr int S2_PLB = DMAP ? 16384 : S2_MAXSLOTS * 32;
   __shared__ __attribute__((aligned(16))) float lnp_s[LNP ? 1024 : 4];      // gamma[0..511], beta at +512 (C <= 512: host check)
   constexpr int BAND = 32 * MT;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * S2_PLB];
@@ -136,7 +156,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     band_geometry(band, pg_first, nrows);
 #pragma unroll
     for (int j = 0; j < S2_NPASS; ++j) {
-      const int slot = (tid + 256 * j) >> 1, half = tid & 1;
+      const int slot = (tid + 256 * j) >> 1;
+      // (DMAP: lane writes LDS position tid & 1 of its slot, so it fetches the half the swizzle puts there)
+      const int half = DMAP ? ((tid & 1) ^ S2_SWZ(slot)) : (tid & 1);
       const int lr = slot / p.pitch, lc = slot - lr * p.pitch;
       const int pg = pg_first + lr;
       const int b = pg / Hp;
@@ -193,6 +215,38 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * S2_PLB + lds_off) = pl[pp];
       }
+    }
+  };
+
+  // DMAP: the four (slot, half) items of this lane as four DMA instructions per plane (instruction j of wave w fills LDS bytes
+  // [1024 w + 4096 j, + 1024) of a plane: items 64 w + 256 j .. + 63, lane l at + 16 l); then the staging state advances like stage_load
+  const unsigned s2_rs[4] = {(unsigned)reinterpret_cast<unsigned long long>(p.src), (unsigned)(reinterpret_cast<unsigned long long>(p.src) >> 32) & 0xffffu,
+                             p.src_bytes, 0x00020000u};
+  auto stage_dma = [&](unsigned char* dst) __attribute__((always_inline)) {
+    typedef int s2_v4i __attribute__((ext_vector_type(4)));
+    const s2_v4i rs = s2_v4i{(int)s2_rs[0], (int)s2_rs[1], (int)s2_rs[2], (int)s2_rs[3]};
+    int cls, cc;
+    if constexpr (DGRAD) { cls = s_stage / nch; cc = s_stage - cls * nch; }
+    else { cc = s_stage >> 2; cls = s_stage & 3; }
+    (void)cls;
+    cc += cbeg;
+    unsigned uni = (unsigned)(cc * 64);
+    if constexpr (!DGRAD) uni += (unsigned)((((cls < 2 ? 1 : 0) * 2 * p.Wo + ((cls & 1) ? 0 : 1)) * p.C) * 4);
+    const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)dst + (unsigned)wave * 1024u;
+#pragma unroll
+    for (int j = 0; j < S2_NPASS; ++j) {
+      const unsigned off = s_base[j] == SGG_OOB ? SGG_OOB : s16_hi_off(s_base[j] + uni);
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :
+                     : "s"(la + (unsigned)(j * 4096 + pp * S2_PLB)), "v"(off), "s"(rs), "s"(pp * 64)
+                     : "memory");
+    }
+    if (++s_stage == nstage) {
+      s_stage = 0;
+      s_band += bstride;
+      stage_band(s_band);
     }
   };
 
@@ -264,15 +318,23 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     auto body = [&](auto ti_c) __attribute__((always_inline)) {
       constexpr int ti = decltype(ti_c)::value;
       constexpr int par = (par0 + ti) & 1;
+#if !S2_ABL_NOB
         if constexpr (ti + 1 < ntaps) {
         constexpr int njy = (ti + 1) / nx, njx = (ti + 1) % nx;
         load_b(std::integral_constant<int, par ^ 1>{}, cc, Axis<DGRAD>::k(qy, njy) * 5 + Axis<DGRAD>::k(qx, njx));
       } else {
         load_b(std::integral_constant<int, par ^ 1>{}, next_cc, next_tap);
       }
-      if constexpr (ti == (ntaps >= 6 ? ntaps - 3 : 1)) stage_load();
+#endif
+#if !S2_ABL_NOSTAGE
+      if constexpr (DMAP) {
+        if constexpr (ti == 0) stage_dma(lds + (cur ^ 1) * (P * S2_PLB));
+      } else if constexpr (ti == (ntaps >= 6 ? ntaps - 3 : 1)) stage_load();
+#endif
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ti == ntaps - 1) stage_write(lds + (cur ^ 1) * (P * S2_PLB));
+#if !S2_ABL_NOSTAGE
+      if constexpr (!DMAP && ti == ntaps - 1) stage_write(lds + (cur ^ 1) * (P * S2_PLB));
+#endif
       auto tile = [&](auto t_c) __attribute__((always_inline)) {
         constexpr int t = decltype(t_c)::value;
         constexpr int k = ti * MT + t;
@@ -296,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     if constexpr (ntaps > 4) { body(std::integral_constant<int, 4>{}); body(std::integral_constant<int, 5>{}); }
     if constexpr (ntaps > 6) { body(std::integral_constant<int, 6>{}); body(std::integral_constant<int, 7>{}); body(std::integral_constant<int, 8>{}); }
     cur ^= 1;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (DMAP) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): this wave's patch DMAs have landed
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
   constexpr int TAP0[4] = {Axis<DGRAD>::k(1, 0) * 5 + Axis<DGRAD>::k(1, 0), Axis<DGRAD>::k(1, 0) * 5 + Axis<DGRAD>::k(0, 0),
@@ -392,12 +455,21 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     __syncthreads();
   }
   stage_band(s_band);
-  stage_load();
-  load_b(std::integral_constant<int, 0>{}, cbeg, TAP0[0]);
-  stage_write(lds);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (DMAP) {
+    stage_dma(lds);
+    load_b(std::integral_constant<int, 0>{}, cbeg, TAP0[0]);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+  } else {
+    stage_load();
+    load_b(std::integral_constant<int, 0>{}, cbeg, TAP0[0]);
+    stage_write(lds);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
 
+#if S2_ABL_NOB
+  load_b(std::integral_constant<int, 1>{}, cbeg, TAP0[0]);
+#endif
   int tabsel = 0;
   for (int band = band_begin; band < band_end; band += bstride, tabsel ^= 1) {
     // compute state of this band: row table (out offsets) and the per-lane patch slots of the 7 row tiles
@@ -440,7 +512,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
         stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, cc + 1, cc + 1, TAP0[3]);
         stage(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, cc + 1, last ? cbeg : cc + 2, TAP0[0]);
       }
+#if !S2_ABL_NOEPI
       epilogue(band, tabsel, 0);
+#endif
     } else {
       auto class_loop = [&](auto cls_c) __attribute__((always_inline)) {
         constexpr int cls = decltype(cls_c)::value;
@@ -451,7 +525,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
           stage(cls_c, std::integral_constant<int, 0>{}, cc, cc + 1, TAP0[cls]);
           stage(cls_c, std::integral_constant<int, odd>{}, cc + 1, last ? cbeg : cc + 2, last ? TAP0[ncls] : TAP0[cls]);
         }
+#if !S2_ABL_NOEPI
         epilogue(band, tabsel, ((cls_qy(cls) * 2 * p.Wo + cls_qx(cls)) * p.N) * 4);
+#endif
       };
       class_loop(std::integral_constant<int, 0>{});
       class_loop(std::integral_constant<int, 1>{});
@@ -459,6 +535,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       class_loop(std::integral_constant<int, 3>{});
     }
   }
+#if S2_ABL_NOEPI
+  epilogue(band_begin, 0, 0);      // (keeps the accumulators alive: once per workgroup)
+#endif
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
@@ -507,6 +586,16 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx));
   const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);
+  if (S2_DMA && p.src_s16 && half && !one && !p.ln_stats) {      // pre-split source: the patch by LDS-DMA
+    if (mt == 4) {
+      if (dgrad) hipLaunchKernelGGL((conv_s2_kernel<true, true, 4, false, false, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((conv_s2_kernel<false, true, 4, false, false, true>), grid, dim3(256), 0, st, p);
+    } else {
+      if (dgrad) hipLaunchKernelGGL((conv_s2_kernel<true, true, 7, false, false, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((conv_s2_kernel<false, true, 7, false, false, true>), grid, dim3(256), 0, st, p);
+    }
+    return;
+  }
   if (p.ln_stats) {       // LN prologue: forward, two-piece modes, 224-position bands (host checks in sgg_conv2d_nhwc_fwd)
     if (half) hipLaunchKernelGGL((conv_s2_kernel<false, true, 7, false, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((conv_s2_kernel<false, false, 7, false, true>), grid, dim3(256), 0, st, p);

@@ -624,9 +624,13 @@ extern "C" size_t sgg_conv2d_nhwc_wgrad_workspace_bytes(int B, int Hi, int Wi, i
 #ifndef SGG_WGRAD_DMA
 #define SGG_WGRAD_DMA 1
 #endif
+// 0: per-tap kernels (or conv1_1's own); 1: the halo-resident kernel (takes pre-split operands, stages them through registers);
+// 2: with BOTH operands pre-split in precision 2 the LDS-DMA kernel runs instead (conv_wgrad_dma.hip)
 extern "C" int sgg_conv2d_nhwc_wgrad_resident(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision) {
   WgradHaloPlan hp;
-  return sgg_prec_resident(precision) && Cin != 3 && B > 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp) ? 1 : 0;
+  if (!(sgg_prec_resident(precision) && Cin != 3 && B > 0 && sgg_wgrad_halo_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &hp))) return 0;
+  WgradDmaPlan dp;
+  return (SGG_WGRAD_DMA && precision == 2 && sgg_wgrad_dma_plan(B, Ho, Wo, Cin, Cout, KH, KW, stride, &dp)) ? 2 : 1;
 }
 
 extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, int B, int Hi, int Wi, int Cin, int Ho,

@@ -356,9 +356,12 @@ class HipKernels:
         return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], k, k, stride, self.conv_precision,
                                                        layout)
 
-    def halo_pc_symbol(self, lnp=False):
-        """Kernel symbol of the producer / consumer 3x3 kernel (csrc/conv_halo_pc.hip; w_split_layout 4)."""
-        return "conv_halo3_pc_kernel<%s,%s>" % ("true" if self.conv_precision == 2 else "false", "true" if lnp else "false")
+    def halo_pc_symbol(self, lnp=False, presplit=False):
+        """Kernel symbol of the producer / consumer 3x3 kernel (csrc/conv_halo_pc.hip; w_split_layout 4); presplit: the source is a
+        pre-split tensor, the patch is staged by LDS-DMA (third template argument)."""
+        dma = presplit and not lnp and self.conv_precision == 2
+        return "conv_halo3_pc_kernel<%s,%s,%s>" % ("true" if self.conv_precision == 2 else "false", "true" if lnp else "false",
+                                                   "true" if dma else "false")
 
     def halo_symbol(self, n_out, n_in, lnp=False):
         """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_halo.hip: sgg_halo_launch picks (default build)."""
@@ -386,7 +389,7 @@ class HipKernels:
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_pc_symbol(ln is not None) if w_split_layout == 4 else
+        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_pc_symbol(ln is not None, x_s16) if w_split_layout == 4 else
                                                              self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
                                                              self.halo_symbol(d[6], 4 * d[3], ln is not None) if w_split_layout == 3 else
                                                              self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None, ln is not None) if w_split_layout == 2 else
@@ -407,7 +410,7 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        sym = self.halo_pc_symbol() if w_split_layout == 4 else self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
+        sym = self.halo_pc_symbol(False, dy_s16) if w_split_layout == 4 else self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
                                                                           self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False) if w_split_layout == 2 else
                                                                           self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
@@ -430,6 +433,9 @@ class HipKernels:
         ws = self.workspace(need)
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         sym, nb = "conv_wgrad(call: wgrad kernel + slab reduce)", 0.0
+        if x_s16 and dy_s16 and ln is None and self.conv_precision == 2 and self.conv_halo and \
+                self.lib.sgg_conv2d_nhwc_wgrad_resident(d[0], d[4], d[5], d[3], d[6], d[7], d[8], stride, 2) == 2:
+            sym = "conv_wgrad_dma(call: LDS-DMA kernel on pre-split operands + slab reduce)"
         if d[3] != 3:
             amax_x, amax_dy = self._amax_or_compute(x, amax_x, 0), self._amax_or_compute(dy, amax_dy, 1)
         else:

@@ -177,9 +177,10 @@ def test_step_runs_the_kernels_the_routing_names(hip):
     finally:
         hip.timing, hip.ln_fusion = None, old
     count = lambda prefix: sum(s.startswith(prefix) for s in syms)
-    assert count("conv_halo3_pc_kernel<true,false>") >= 6, sorted(set(syms))          # dgrads of conv2_4, conv3_1, conv3_2 in both networks
+    # dgrads of conv2_4, conv3_1, conv3_2 in both networks (third template argument: the patch staged by LDS-DMA from a pre-split dy)
+    assert count("conv_halo3_pc_kernel<true,false,") >= 6, sorted(set(syms))
     assert count("conv_halo3_kernel<2,128,2,2,true,true,false,true,false,1>") >= 6, sorted(set(syms))     # LN-prologue forwards
-    assert count("conv_halo3_pc_kernel<true,true>") == 0 and count("conv_gather") == 0, sorted(set(syms))
+    assert count("conv_halo3_pc_kernel<true,true,") == 0 and count("conv_gather") == 0, sorted(set(syms))
 
 
 @pytest.mark.gpu
