@@ -3,7 +3,7 @@
 #   b: the two PMC passes, configs[3] and configs[4] lines
 set -e
 PART=${1:-a}
-TAG=${2:-r03}
+TAG=${2:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O

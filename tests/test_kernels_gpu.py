@@ -582,6 +582,10 @@ S2_CASES = [
     (20, 8, 32, 128),       # 4x4 grid: a band of 128 positions spans 8 images (each with its own zero rows in the padded row space)
     (24, 112, 32, 128),     # 336 bands of 224 positions: more work items than CUs -> the 7-tile variant (the small cases above run
                             # the 4-tile variant unless LayerNorm partials are requested)
+    # round 4: more shapes whose bands cross image boundaries mid-row (added with the balanced-band experiment)
+    (12, 28, 64, 128),      # 14x14 grid: 10.5 bands, every band crosses an image boundary mid-row
+    (9, 56, 64, 256),       # 28x28 grid: 31.5 bands (ragged last band and row tile), two n-tiles
+    (160, 8, 32, 128),      # 4x4 grid: a band spans fourteen images
 ]
 
 
