@@ -47,7 +47,6 @@
 #define S2_BAND 224                   // positions per band in the 7-tile variant (what LayerNorm partials are defined on)
 #define S2_MAXSLOTS 496               // 2 buffers x 2 planes x 496 x 32 B + the row tables stay inside 64 KB of static LDS
 #define S2_ZSLOT (S2_MAXSLOTS - 1)    // never part of a patch: staged as zeros (out-of-range loads), read by edge lanes
-#define S2_NPASS 4                     // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256
 #define S2_BN 128
 #ifndef S2_SMALL_ITEMS
 #define S2_SMALL_ITEMS 256            // at most this many 224-position work items: use 128-position bands instead
@@ -60,6 +59,9 @@
 #endif
 #ifndef S2_DMA
 #define S2_DMA 1              // 0: a pre-split source is staged through registers (no arithmetic) like an f32 one
+#endif
+#ifndef S2_WIDE
+#define S2_WIDE 1             // 0: always 128-column workgroups
 #endif
 #ifndef S2_SWZ
 #define S2_SWZ(slot) (((slot) >> 3) & 1)      // which 16-B half of a slot holds channels 0..7
@@ -90,8 +92,15 @@ constexpr int cls_ntaps(int cls) { return (cls_qy(cls) ? 3 : 2) * (cls_qx(cls) ?
 // DMAP: src is a PRE-SPLIT tensor (split16.h; HALF, two pieces, no prologue): the patch goes HBM -> LDS by LDS-DMA (inline assembly:
 // invisible to the compiler's wait-count pass, waited for by an explicit s_waitcnt at the end of the stage), issued at the stage's
 // FIRST tap into the buffer the workgroup left at the last barrier - no staging registers, loads, conversions or LDS writes.
-template <bool DGRAD, bool HALF, int MT, bool ONE = false, bool LNP = false, bool DMAP = false>
-__global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
+// NW: waves per workgroup = 32-column slices of the band it owns: 4 (128 output columns, two workgroups per CU) or 8 (256 columns, ONE
+// workgroup per CU: the band's patch is staged once per 256 instead of once per 128 output columns - half the x traffic of the layers
+// with 256+ output channels; DMAP only).
+template <bool DGRAD, bool HALF, int MT, bool ONE = false, bool LNP = false, bool DMAP = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_s2_kernel(S2Params p) {
+  static_assert(NW == 4 || (NW == 8 && DMAP), "256-column workgroups: patch by DMA only");
+  constexpr int NT = 64 * NW;                 // threads
+  constexpr int BN = 32 * NW;                 // output columns per workgroup
+  constexpr int NPASS = 1024 / NT;            // (slot, 8-channel half) items per thread: 992 -> 4 passes of 256 / 2 of 512
   static_assert(!LNP || (!DGRAD && !ONE), "the LN prologue exists for the forward of the two-piece modes");
   static_assert(!DMAP || (HALF && !ONE && !LNP), "patch DMA: pre-split fp16 pieces, no prologue");
   constexpr int P = ONE ? 1 : 2;
@@ -103,17 +112,17 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   __shared__ __attribute__((aligned(16))) int rowtab[2][BAND];      // byte offset of each band row in `out` (-1: past the end)
 
   // ---- persistent workgroup: XCD k owns a contiguous eighth of the bands; its p.gx workgroups walk (band, n-tile) pairs -----
-  const int ntn = (p.N / S2_BN) * p.ksplit;                  // (n-tile, channel half) pairs: static per workgroup
+  const int ntn = (p.N / BN) * p.ksplit;                     // (n-tile, channel half) pairs: static per workgroup
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int ntk = jx % ntn;
-  const int nt = ntk % (p.N / S2_BN), khalf = ntk / (p.N / S2_BN);
+  const int nt = ntk % (p.N / BN), khalf = ntk / (p.N / BN);
   const int bstride = p.gx / ntn;
   const int band_begin = (int)(((long long)xcd * p.nbands) >> 3) + jx / ntn;
   const int band_end = (int)(((long long)(xcd + 1) * p.nbands) >> 3);
   if (band_begin >= band_end) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = nt * S2_BN + wave * 32;                     // this wave's 32 output channels
+  const int n0 = nt * BN + wave * 32;                     // this wave's 32 output channels
   const int i = lane & 31, h = lane >> 5;
 
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
@@ -134,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   // (patch row / column are recomputed once per band and the LDS offset per write: cheaper than 12 live registers)
   // staging state (runs ahead of the compute state): band, stage inside the band, per-item source offsets of that band
   int s_band = band_begin, s_stage = 0;
-  unsigned s_base[S2_NPASS];
-  int s_b[LNP ? S2_NPASS : 1];              // LN prologue: sample of each item of the band being staged
-  float ld_mu[LNP ? S2_NPASS : 1], ld_rs[LNP ? S2_NPASS : 1];     // ... and the (mean, rstd) / chunk of the patch in flight
+  unsigned s_base[NPASS];
+  int s_b[LNP ? NPASS : 1];              // LN prologue: sample of each item of the band being staged
+  float ld_mu[LNP ? NPASS : 1], ld_rs[LNP ? NPASS : 1];     // ... and the (mean, rstd) / chunk of the patch in flight
   int ld_cc = 0, ld_bad = 0;
   auto band_geometry = [&](int band, int& pg_first, int& nrows) __attribute__((always_inline)) {
     const int p0 = band * BAND;
@@ -149,14 +158,14 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   auto stage_band = [&](int band) __attribute__((always_inline)) {
     if (band >= band_end) {
 #pragma unroll
-      for (int j = 0; j < S2_NPASS; ++j) s_base[j] = SGG_OOB;
+      for (int j = 0; j < NPASS; ++j) s_base[j] = SGG_OOB;
       return;
     }
     int pg_first, nrows;
     band_geometry(band, pg_first, nrows);
 #pragma unroll
-    for (int j = 0; j < S2_NPASS; ++j) {
-      const int slot = (tid + 256 * j) >> 1;
+    for (int j = 0; j < NPASS; ++j) {
+      const int slot = (tid + NT * j) >> 1;
       // (DMAP: lane writes LDS position tid & 1 of its slot, so it fetches the half the swizzle puts there)
       const int half = DMAP ? ((tid & 1) ^ S2_SWZ(slot)) : (tid & 1);
       const int lr = slot / p.pitch, lc = slot - lr * p.pitch;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       if constexpr (LNP) s_b[j] = b < p.B ? b : p.B - 1;
     }
   };
-  f32x4 pre[S2_NPASS][2];
+  f32x4 pre[NPASS][2];
   // issue the global loads of the next (band, stage) patch; then advance the staging state
   auto stage_load = [&]() __attribute__((always_inline)) {
     int cls, cc;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     if constexpr (!DGRAD) uni += (unsigned)((((cls < 2 ? 1 : 0) * 2 * p.Wo + ((cls & 1) ? 0 : 1)) * p.C) * 4);
     if constexpr (LNP) { ld_cc = cc; ld_bad = 0; }
 #pragma unroll
-    for (int j = 0; j < S2_NPASS; ++j) {
+    for (int j = 0; j < NPASS; ++j) {
       const unsigned off = s_base[j] == SGG_OOB ? SGG_OOB : s_base[j] + uni;
       const unsigned o0 = LNP ? off : stage_off0(off, p.src_s16);
       pre[j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, o0);
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   };
   auto stage_write = [&](unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < S2_NPASS; ++j) {
+    for (int j = 0; j < NPASS; ++j) {
       if constexpr (LNP) {
         const int ch0 = ld_cc * 16 + (tid & 1) * 8;
         ln_elu8(pre[j][0], pre[j][1], lnp_s + ch0, lnp_s + 512 + ch0, ld_mu[j], ld_rs[j], (ld_bad >> j) & 1);
@@ -209,8 +218,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
       u32x4 pl[P];
       if constexpr (LNP || !HALF) split8<P, HALF>(pre[j][0], pre[j][1], sa, pl);
       else stage_planes<P, HALF>(pre[j][0], pre[j][1], sa, p.src_s16, pl);
-      if (tid + 256 * j < 2 * S2_MAXSLOTS) {
-        const int slot = (tid + 256 * j) >> 1;
+      if (tid + NT * j < 2 * S2_MAXSLOTS) {
+        const int slot = (tid + NT * j) >> 1;
         const int lds_off = slot * 32 + (((tid & 1) ^ S2_SWZ(slot)) << 4);
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * S2_PLB + lds_off) = pl[pp];
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
   };
 
   // DMAP: the four (slot, half) items of this lane as four DMA instructions per plane (instruction j of wave w fills LDS bytes
-  // [1024 w + 4096 j, + 1024) of a plane: items 64 w + 256 j .. + 63, lane l at + 16 l); then the staging state advances like stage_load
+  // [1024 w + 16 NT j, + 1024) of a plane: items 64 w + NT j .. + 63, lane l at + 16 l); then the staging state advances like stage_load
   const unsigned s2_rs[4] = {(unsigned)reinterpret_cast<unsigned long long>(p.src), (unsigned)(reinterpret_cast<unsigned long long>(p.src) >> 32) & 0xffffu,
                              p.src_bytes, 0x00020000u};
   auto stage_dma = [&](unsigned char* dst) __attribute__((always_inline)) {
@@ -234,13 +243,13 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
     if constexpr (!DGRAD) uni += (unsigned)((((cls < 2 ? 1 : 0) * 2 * p.Wo + ((cls & 1) ? 0 : 1)) * p.C) * 4);
     const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)dst + (unsigned)wave * 1024u;
 #pragma unroll
-    for (int j = 0; j < S2_NPASS; ++j) {
+    for (int j = 0; j < NPASS; ++j) {
       const unsigned off = s_base[j] == SGG_OOB ? SGG_OOB : s16_hi_off(s_base[j] + uni);
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :
-                     : "s"(la + (unsigned)(j * 4096 + pp * S2_PLB)), "v"(off), "s"(rs), "s"(pp * 64)
+                     : "s"(la + (unsigned)(j * (NT * 16) + pp * S2_PLB)), "v"(off), "s"(rs), "s"(pp * 64)
                      : "memory");
     }
     if (++s_stage == nstage) {
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_kernel(S2Params p) {
 
   // ---- prologue: first patch, first B fragments ----------------------------------------------------------------------------
   if constexpr (LNP) {
-    for (int c = tid; c < p.C; c += 256) {
+    for (int c = tid; c < p.C; c += NT) {
       lnp_s[c] = p.ln_gamma[c];
       lnp_s[512 + c] = p.ln_beta[c];
     }
@@ -571,22 +580,32 @@ int sgg_s2_stats_per_sample(int Ho, int Wo, int N) { return ((Ho * Wo) % S2_BAND
 
 void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st) {
   S2Params p = p_;
+  const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);
+  const bool dmap = S2_DMA && p.src_s16 && half && !one && !p.ln_stats;      // pre-split source: the patch by LDS-DMA
+  // 256-column workgroups (eight waves, one workgroup per CU) where the layer has 256+ output columns and the patch comes by DMA
+  const bool wide = S2_WIDE && dmap && p.N % 256 == 0;
+  const int bn = wide ? 256 : S2_BN;
   // 224-position bands unless they give fewer work items than CUs (and no LayerNorm partials are asked for): then 128-position
   // bands (S2_KSPLIT_MODE 0), or 224-position bands with the channel chunks split over two workgroups (1), or both (2)
-  const bool small_ = !p.tile_stats && !p.ln_stats && sgg_cdiv(p.M, S2_BAND) * (p.N / S2_BN) <= S2_SMALL_ITEMS;
-  const int mt = (small_ && S2_KSPLIT_MODE != 1) ? 4 : 7;
+  const bool small_ = !p.tile_stats && !p.ln_stats && sgg_cdiv(p.M, S2_BAND) * (p.N / bn) <= (wide ? S2_SMALL_ITEMS / 2 : S2_SMALL_ITEMS);
+  const int mt = (small_ && S2_KSPLIT_MODE != 1 && !wide) ? 4 : 7;
   p.ksplit = (small_ && S2_KSPLIT_MODE != 0 && (p.C >> 4) % 4 == 0) ? 2 : 1;
   if (p.ksplit > 1)
     (void)hipMemsetAsync(p.out, 0, (size_t)(dgrad ? 4 : 1) * p.M * p.N * sizeof(float), st);
-  const int ntn = (p.N / S2_BN) * p.ksplit;
+  const int ntn = (p.N / bn) * p.ksplit;
   p.nbands = sgg_cdiv(p.M, 32 * mt);
+  const int slots = wide ? 32 : 64;                // resident workgroups per XCD (32 CUs)
   int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile, channel half) items an XCD owns
-  int gx = per_xcd < 64 ? per_xcd : 64;            // two resident workgroups on each of its 32 CUs
+  int gx = per_xcd < slots ? per_xcd : slots;
   gx = sgg_cdiv(gx, ntn) * ntn;
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx));
-  const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);
-  if (S2_DMA && p.src_s16 && half && !one && !p.ln_stats) {      // pre-split source: the patch by LDS-DMA
+  if (wide) {
+    if (dgrad) hipLaunchKernelGGL((conv_s2_kernel<true, true, 7, false, false, true, 8>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv_s2_kernel<false, true, 7, false, false, true, 8>), grid, dim3(512), 0, st, p);
+    return;
+  }
+  if (dmap) {
     if (mt == 4) {
       if (dgrad) hipLaunchKernelGGL((conv_s2_kernel<true, true, 4, false, false, true>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((conv_s2_kernel<false, true, 4, false, false, true>), grid, dim3(256), 0, st, p);

@@ -371,11 +371,15 @@ class HipKernels:
                                                            "true" if n_in == 32 else "false", "true" if lnp else "false",
                                                            "true" if self.conv_precision in (1, 4) else "false")
 
-    def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True, lnp=False):
-        """(csrc/conv_s2.hip: 224-position bands; with at most 256 work items the channel chunks are split over two workgroups)"""
+    def s2_symbol(self, dgrad, m_positions=1 << 30, n_out=128, stats=True, lnp=False, presplit=False):
+        """(csrc/conv_s2.hip: 224-position bands; with at most 256 work items the channel chunks are split over two workgroups);
+        presplit: the source is a pre-split tensor, the patch is staged by LDS-DMA (sixth template argument) - by eight-wave
+        workgroups that own 256 output columns where the layer has that many (seventh)"""
         mt = 7
-        return "conv_s2_kernel<%s,%s,%d,%s,%s>" % ("true" if dgrad else "false", "true" if self.conv_precision in (1, 2) else "false", mt,
-                                                   "true" if self.conv_precision in (1, 4) else "false", "true" if lnp else "false")
+        dma = presplit and not lnp and self.conv_precision == 2
+        return "conv_s2_kernel<%s,%s,%d,%s,%s,%s,%d>" % ("true" if dgrad else "false", "true" if self.conv_precision in (1, 2) else "false", mt,
+                                                         "true" if self.conv_precision in (1, 4) else "false", "true" if lnp else "false",
+                                                         "true" if dma else "false", 8 if dma and n_out % 256 == 0 else 4)
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0,
                  ln=None, x_s16=False):
@@ -392,7 +396,7 @@ class HipKernels:
         sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_pc_symbol(ln is not None, x_s16) if w_split_layout == 4 else
                                                              self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
                                                              self.halo_symbol(d[6], 4 * d[3], ln is not None) if w_split_layout == 3 else
-                                                             self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None, ln is not None) if w_split_layout == 2 else
+                                                             self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None, ln is not None, x_s16) if w_split_layout == 2 else
                                                              self.gather_symbol(d[6], w_split is not None))
         nb = 0.0
         if d[3] != 3:
@@ -411,7 +415,7 @@ class HipKernels:
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
         sym = self.halo_pc_symbol(False, dy_s16) if w_split_layout == 4 else self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
-                                                                          self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False) if w_split_layout == 2 else
+                                                                          self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False, False, dy_s16) if w_split_layout == 2 else
                                                                           self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(
             _p(dy), _p(w_hwio), _p(w_split), _p(dx), *d, self.conv_precision, w_split_layout, _p(amax_dy), _p(amax_w),

@@ -130,6 +130,8 @@ FWD_CASES = [
     (2, 16, 16, 128, 128, 5, 2),     # band-resident 5x5 stride 2 (layout 2)
     (2, 16, 16, 256, 512, 5, 2),
     (4, 8, 8, 512, 512, 5, 2),       # few work items: channel chunks split over two workgroups
+    (2, 64, 64, 128, 256, 5, 2),     # 256 output columns: eight-wave workgroups (one patch per 256 columns), 9.1 bands
+    (2, 32, 32, 256, 512, 5, 2),     # ... two of them per band forward, one in the dgrad direction; bands cross the image boundary
 ]
 
 
