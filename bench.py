@@ -9,7 +9,8 @@ Default workload = BASELINE.json configs[1]: batch 64 per GPU, 224x224 synthetic
 gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
 
   value / ms_per_step   the timed region: the product's default schedule (train.py: two HIP streams - D's encoder beside G's forward,
-                        filter gradients beside the dgrad -> LayerNorm-backward chain; bit-identical to the serial order), default conv
+                        filter gradients beside the dgrad -> LayerNorm-backward chain - and a third for the recurrent heads' deferred
+                        parameter-gradient work; bit-identical to the serial order), default conv
                         contraction mode (see DTYPE_NAME); config.schedule says so.  --single-stream times the serial order instead
   serial                the same workload in the serial launch order, right after the timed region (kernels of two streams share the
                         chip, so only serial steps give per-kernel durations): its steps bracket the dominant convolution kernel's launches
@@ -373,9 +374,9 @@ def main():
                     help="conv contraction: 2 = scaled fp16 pieces, 3 products (default), 6 = bf16 pieces, 6 products, "
                          "0 = native f32 MFMA, 3 = bf16 pieces, 3 products (within the 1e-4 tolerance); 1 / 4 = ONE fp16 / bf16 piece, one product "
                          "(mixed precision: not the reference's arithmetic, not a headline)")
-    ap.add_argument("--head-side-stream", action="store_true",
-                    help="A/B switch: everything off the recurrent dependency chain of the heads on a side stream (sgg_amd/head.py; "
-                         "bit-identical results, measured: no gain)")
+    ap.add_argument("--head-side-stream", type=int, default=None, choices=[0, 1],
+                    help="A/B switch: the heads' parameter-gradient work deferred to a stream of its own (sgg_amd/head.py; bit-identical "
+                         "results); default: on with the two-stream schedule, off with --single-stream")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="N > 1: the ranks only meet (process group, one bucket-sized all-reduce through sgg_amd.dp, barrier) and rank 0 "
                          "prints the `rccl` record with value null - the launch path without a workload (CPU rehearsal over gloo)")
@@ -409,8 +410,8 @@ def main():
     two_stream = not args.single_stream
     reducer = dpmod.GradReducer() if world > 1 else None
     gs = GanStep(K, V, S, B, lam=10.0, g_state=init_state_dict("G", V, S), d_state=init_state_dict("D", V, S), reducer=reducer,
-                 overlap_streams=two_stream, head_side_stream=args.head_side_stream)
-    side_stream = gs.side
+                 overlap_streams=two_stream, head_side_stream=None if args.head_side_stream is None else bool(args.head_side_stream))
+    side_stream, head_stream = gs.side, gs.head_side
     kt = not args.no_kernel_timing
     extra = (args.serial_steps + 2) + (2 if kt else 0) + (args.f32_steps + 1 if K.conv_precision != 0 else 0) + (4 if world > 1 else 0)
     total_steps = args.warmup + args.steps
@@ -421,6 +422,9 @@ def main():
         gs.side = side_stream if two else None
         gs.G.trunk.enable_wgrad_overlap(gs.side)
         gs.D.trunk.enable_wgrad_overlap(gs.side)
+        gs.head_side = head_stream if two else None      # (the heads' deferred parameter-gradient work: head.py)
+        gs.G.head.enable_side_stream(gs.head_side)
+        gs.D.head.enable_side_stream(gs.head_side)
 
     def one_step(k):
         base = k * (CI + 1)

@@ -145,6 +145,11 @@ int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, const float* b
  * instead of the maximum: forward - the caller zeroes the word, the call merges the statistics, publishes max over the samples of
  * max|gamma| * max|y - mean| * rstd + max|beta| and applies (three launches; two with tile_stats); backward - max(rstd * max|dxhat|) *
  * (2 + max|xhat|), the two maxima published atomically by the reduction pass into the caller-zeroed words pq. */
+/* An f32 NHWC tensor (n elements, channel count a multiple of 32) -> the PRE-SPLIT format under the scale of *amax (its maximum from
+ * sgg_absmax, or any upper bound): for operands that no LayerNorm kernel produces - the gradient the attention head hands to
+ * `downsampled` (generator_with_attention.py:68,74), whose Conv2DBackpropInput / Conv2DBackpropFilter then stage it by LDS-DMA like
+ * every other layer's.  out may be x (in place). */
+int sgg_presplit16(const float* x, float* out, long long n, const float* amax, void* stream);
 /* statistics only: stats[b] = (mean, rstd) merged from the convolution's tile partials; amax_out max-ed with an upper bound of
  * max|ELU(LN(y))| (for the fp16 scaling of a consumer with an LN prologue) */
 int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_stats, const float* gamma, const float* beta, float* stats,

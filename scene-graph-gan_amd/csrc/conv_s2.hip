@@ -583,12 +583,13 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
   const bool half = sgg_prec_half(precision), one = sgg_prec_one(precision);
   const bool dmap = S2_DMA && p.src_s16 && half && !one && !p.ln_stats;      // pre-split source: the patch by LDS-DMA
   // 256-column workgroups (eight waves, one workgroup per CU) where the layer has 256+ output columns and the patch comes by DMA
-  const bool wide = S2_WIDE && dmap && p.N % 256 == 0;
+  // (not where that leaves fewer work items than half the CUs - `downsampled` at batch 64: measured equal forward, 7 % slower dgrad)
+  const bool wide = S2_WIDE && dmap && p.N % 256 == 0 && sgg_cdiv(p.M, S2_BAND) * (p.N / 256) > S2_SMALL_ITEMS / 2;
   const int bn = wide ? 256 : S2_BN;
   // 224-position bands unless they give fewer work items than CUs (and no LayerNorm partials are asked for): then 128-position
   // bands (S2_KSPLIT_MODE 0), or 224-position bands with the channel chunks split over two workgroups (1), or both (2)
-  const bool small_ = !p.tile_stats && !p.ln_stats && sgg_cdiv(p.M, S2_BAND) * (p.N / bn) <= (wide ? S2_SMALL_ITEMS / 2 : S2_SMALL_ITEMS);
-  const int mt = (small_ && S2_KSPLIT_MODE != 1 && !wide) ? 4 : 7;
+  const bool small_ = !wide && !p.tile_stats && !p.ln_stats && sgg_cdiv(p.M, S2_BAND) * (p.N / bn) <= S2_SMALL_ITEMS;
+  const int mt = (small_ && S2_KSPLIT_MODE != 1) ? 4 : 7;
   p.ksplit = (small_ && S2_KSPLIT_MODE != 0 && (p.C >> 4) % 4 == 0) ? 2 : 1;
   if (p.ksplit > 1)
     (void)hipMemsetAsync(p.out, 0, (size_t)(dgrad ? 4 : 1) * p.M * p.N * sizeof(float), st);

@@ -658,6 +658,30 @@ extern "C" int sgg_layernorm_hwc_elu_fwd(const float* y, const float* gamma, con
   return SGG_OK;
 }
 
+// An f32 tensor that no LayerNorm kernel produces (the gradient the attention head hands to `downsampled`,
+// architectures/generator_with_attention.py:68,74) converted to the pre-split format, so that its consumers stage it by DMA too.
+__global__ __launch_bounds__(256) void presplit16_kernel(const float* __restrict__ x, float* __restrict__ out, long long n,
+                                                         const float* __restrict__ amax) {
+  const float scale = ldexpf(1.f, scale_exp_from_amax(*amax));
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {      // (uniform per workgroup:
+    const long long e = base + threadIdx.x * 4;                                                            //  every lane exchanges)
+    const bool in = e < n;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (in) v = ln_ld(x + e);
+    s16_store4(out, e, v, scale, in);
+  }
+}
+
+extern "C" int sgg_presplit16(const float* x, float* out, long long n, const float* amax, void* stream) {
+  SGG_CHECK_ARG(x && out && amax && n > 0 && n % 32 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0,
+                "sgg_presplit16: needs whole 32-channel groups (n %% 32 == 0) and 16-byte aligned tensors");
+  long long wgs = (n + 1023) / 1024;
+  if (wgs > 2048) wgs = 2048;
+  hipLaunchKernelGGL(presplit16_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, x, out, n, amax);
+  SGG_LAUNCH_CHECK("sgg_presplit16");
+  return SGG_OK;
+}
+
 // Statistics without the apply pass, for consumers that normalise y on the fly (LN prologue of sgg_conv2d_nhwc_fwd / _wgrad):
 // stats[b] = (mean, rstd) from the convolution's tile partials, and amax_out max-ed with an upper bound of max|ELU(LN(y))|.
 extern "C" int sgg_layernorm_hwc_finalize(const float* tile_stats, int n_tile_stats, const float* gamma, const float* beta, float* stats,

@@ -89,8 +89,9 @@ class Head:
         # dgrad -> attention backward -> score dgrad  per step backward - a few short dependent launches each; the embedding and
         # decoder products of the forward pass and every parameter-gradient GEMM / column sum of the backward pass hang off it and
         # only have to be complete at the end of the pass.  On one stream they sit between the chain's launches (~330 dependent
-        # launches of 5-15 us per G+D step); on the side stream they run beside it.  Same kernels, same operands, same accumulation
-        # order (one side stream, program order) -> bit-identical results.
+        # launches of 5-15 us per G+D step).  With a side stream the backward pass DEFERS its parameter-gradient work (95 of those
+        # launches) to it behind one fork per pass (see backward); nothing waits for it until join().  Same kernels, same operands,
+        # same accumulation order (one side stream, program order) -> bit-identical results.
         self.side = None
         self.P = z(B, L)
         self.dP = z(B, L)
@@ -134,38 +135,32 @@ class Head:
         train.py:173) - their embedding product tf.matmul(indices, W) (discriminator_with_attention.py:87) is a row gather.
         Fills st.OUT [np, R, 3, Vout]."""
         K, np_, R, ind = self.K, st.np, st.R, self.in_dim
-        import contextlib
-        on = lambda strm: torch.cuda.stream(strm) if strm is not None else contextlib.nullcontext()
-        # ---- off the chain, known before the loop: the inputs u_t of all three steps (noise copies / embedding products) ----------
-        side = self._fork()
-        with on(side):
-            for t in range(T_STEPS):
-                if self.kind == "G":
-                    st.XH[t][0][:, C:ind].copy_(u)
-                    continue
-                for pl in range(np_):
-                    if labels is not None and pl == 0:
-                        lo, hi = label_rows
-                        for a, b in ((0, lo), (hi, R)):
-                            if b > a:
-                                K.gemm_nn(u[0][a:b, t, :], self.W_emb, st.XH[t][0][a:b, C:ind])
-                        K.embed_gather_fwd(labels[:, t], self.W_emb, st.XH[t][0][lo:hi, C:ind])
-                    else:
-                        K.gemm_nn(u[pl][:, t, :], self.W_emb, st.XH[t][pl][:, C:ind])
+        # (the forward pass runs on ONE stream: its off-chain products - the inputs u_t, the decoder - are read right after the pass,
+        #  and a join here would also wait for the parameter-gradient work an earlier pass left on the side stream)
+        # ---- known before the loop: the inputs u_t of all three steps (noise copies / embedding products) ------------------------
+        for t in range(T_STEPS):
+            if self.kind == "G":
+                st.XH[t][0][:, C:ind].copy_(u)
+                continue
+            for pl in range(np_):
+                if labels is not None and pl == 0:
+                    lo, hi = label_rows
+                    for a, b in ((0, lo), (hi, R)):
+                        if b > a:
+                            K.gemm_nn(u[0][a:b, t, :], self.W_emb, st.XH[t][0][a:b, C:ind])
+                    K.embed_gather_fwd(labels[:, t], self.W_emb, st.XH[t][0][lo:hi, C:ind])
+                else:
+                    K.gemm_nn(u[pl][:, t, :], self.W_emb, st.XH[t][pl][:, C:ind])
         K.spatial_mean_fwd(ctx, st.C[0][0], st.XH[0][0][:, ind:])       # plane 1 (tangent of c0 = h0) stays zero
         for t in range(T_STEPS):
             K.gemm_nn(flat2(st.C[t]), self.W_c, flat2(st.EC[t]))
             K.attn_step_fwd(self.P, st.EC[t], ctx, st.AL[t], st.XH[t][:, :, :C])
-            if t == 0:
-                self.join()                                             # the inputs of every step are in place
             K.gemm_nn(flat2(st.XH[t]), self.Kk, flat2(st.G[t]))
             K.lstm_fwd(st.G[t], st.C[t], self.ln, st.C[t + 1], st.XH[t + 1][:, :, ind:])
-            # ---- off the chain: the decoder (its output is read after the loop) ---------------------------------------------------
-            with on(self._fork()):
-                K.gemm_nn(st.XH[t + 1][0][:, ind:], self.W_dec, st.OUT[0][:, t, :], self.b_dec)
-                if np_ == 2:
-                    K.gemm_nn(st.XH[t + 1][1][:, ind:], self.W_dec, st.OUT[1][:, t, :])
-        self.join()
+            # the decoder (its output is read after the loop)
+            K.gemm_nn(st.XH[t + 1][0][:, ind:], self.W_dec, st.OUT[0][:, t, :], self.b_dec)
+            if np_ == 2:
+                K.gemm_nn(st.XH[t + 1][1][:, ind:], self.W_dec, st.OUT[1][:, t, :])
         return st.OUT
 
     # ------------------------------------------------------------------------------------------------
@@ -189,13 +184,21 @@ class Head:
         on = lambda strm: torch.cuda.stream(strm) if strm is not None else contextlib.nullcontext()
         pc = np_ - 1                                    # plane holding cotangents of real quantities
         assert R_w % self.B == 0 and (np_ == 1 or R_w == R)
+        # Everything OFF the chain (every parameter-gradient GEMM and column sum) reads buffers that stay untouched until the next
+        # pass on this state.  Without a side stream it runs where it stands; with one it is DEFERRED: collected here, enqueued on the
+        # side stream behind ONE fork at the end of the pass, and joined only before the gradients are read (GanStep: head.join()
+        # before the optimiser) - the chain, and after it the encoder backward, never wait for it.  Same kernels, same operands, same
+        # accumulation order per gradient tensor (one side stream, program order): bit-identical.
+        deferred = []
+        off = (lambda fn: deferred.append(fn)) if self.side is not None else (lambda fn: fn())
         # ---- off the chain, known before the loop: the decoder's parameter gradients (operands: the forward's h_t and dOUT) --------
         if R_w:
-            with on(self._fork()):
+            def dec_grads():
                 for t in range(T_STEPS - 1, -1, -1):
                     dout = st.dOUT[:, :, t, :]
                     self._wgrad(st.XH[t + 1][:, :, ind:], dout, self.gW_dec, R_w)
                     K.colsum(dout[pc][:R_w], self.gb_dec, True)
+            off(dec_grads)
         for t in range(T_STEPS - 1, -1, -1):
             dout = st.dOUT[:, :, t, :]
             dh = st.dXH[t + 1][:, :, ind:]
@@ -213,7 +216,7 @@ class Head:
             K.gemm_nt(flat2(dE), self.W_c, flat2(st.dC[t]), accumulate=True)
             # ---- off the chain: the parameter gradients of step t (gate kernel, embedding, score weights), in the serial order ------
             if R_w:
-                with on(self._fork()):
+                def step_grads(t=t, dG=dG, dE=dE):
                     self._wgrad(st.XH[t], dG, self.gKk, R_w)
                     if self.kind == "D":
                         if labels is not None and np_ == 1:
@@ -226,12 +229,18 @@ class Head:
                         else:
                             self._wgrad([x[:, t, :] for x in u], st.dXH[t][:, :, C:ind], self.gW_emb, R_w)
                     self._wgrad(st.C[t], dE, self.gW_c, R_w)
+                off(step_grads)
         if R_w:
             K.spatial_mean_bwd(st.dC[0][pc][:R_w], st.dXH[0][pc][:R_w, ind:], self.dctx, True)
-            with on(self._fork()):
+
+            def ln_grads():
                 for t in range(T_STEPS):
                     K.colsum(st.pgrad[t * R:t * R + R_w].view(R_w, 10 * H), self.gln, True)
-        self.join()
+            off(ln_grads)
+        if deferred:
+            with on(self._fork()):
+                for fn in deferred:
+                    fn()
 
     def finish_backward(self, ctx):
         """Gradients that flow through the step-invariant score P (after every head pass of the step)."""

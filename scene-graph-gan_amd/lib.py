@@ -37,6 +37,7 @@ SIGNATURES = {
     "sgg_conv_split_weights_frag16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sgg_conv2d_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgg_conv2d_nhwc_fwd_tile_stats": (_i, [_i] * 9),
+    "sgg_presplit16": (_i, [_vp, _vp, _ll, _vp, _vp]),
     "sgg_conv2d_nhwc_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _i, _vp]),
     "sgg_conv2d_nhwc_wgrad_workspace_bytes": (_sz, [_i] * 9),
     "sgg_conv2d_nhwc_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
@@ -153,6 +154,9 @@ DEFAULT_OPTIONS = {
     "ln_fusion": 1,
     # True: the LayerNorm kernels write their outputs pre-split for the convolutions that consume them (trunk._plan_s16; fp16 modes)
     "presplit": True,
+    # True (with presplit): the gradient the attention head hands to the last convolution is converted to the pre-split format once
+    # per backward (sgg_presplit16), so that `downsampled`'s dgrad and filter gradient stage it by DMA as well
+    "presplit_head_grad": True,
     # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward /
     # never fuse in passes with backward
     "ln_fusion_skip": (),
@@ -283,6 +287,13 @@ class HipKernels:
         assert x.is_contiguous()
         self._check(self.lib.sgg_absmax(_p(x), x.numel(), _p(amax), self._stream()), "sgg_absmax")
 
+    def presplit16(self, x, out, amax):
+        """out = x in the pre-split format of the LayerNorm kernels (ln_elu_fwd(..., out_s16=True)) under the scale of the word `amax`
+        (max|x| or a bound); x: contiguous f32 NHWC with C % 32 == 0; out: same shape (may be x)."""
+        self._dev(x, out, amax)
+        assert x.is_contiguous() and out.is_contiguous() and out.numel() == x.numel() and x.shape[-1] % 32 == 0
+        self._check(self.lib.sgg_presplit16(_p(x), _p(out), x.numel(), _p(amax), self._stream()), "sgg_presplit16")
+
     def _amax_or_compute(self, t, amax, slot):
         """precision 2 needs max|t| on the device; callers that track it pass `amax`, otherwise it is computed here."""
         if self.conv_precision not in (1, 2) or amax is not None or t is None:
@@ -379,7 +390,8 @@ class HipKernels:
         dma = presplit and not lnp and self.conv_precision == 2
         return "conv_s2_kernel<%s,%s,%d,%s,%s,%s,%d>" % ("true" if dgrad else "false", "true" if self.conv_precision in (1, 2) else "false", mt,
                                                          "true" if self.conv_precision in (1, 4) else "false", "true" if lnp else "false",
-                                                         "true" if dma else "false", 8 if dma and n_out % 256 == 0 else 4)
+                                                         "true" if dma else "false",
+                                                         8 if dma and n_out % 256 == 0 and -(-m_positions // 224) * (n_out // 256) > 128 else 4)
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0,
                  ln=None, x_s16=False):

@@ -92,7 +92,7 @@ class GanStep:
     across data-parallel ranks and returns the scale to apply to the gradient (1/world_size)."""
 
     def __init__(self, K, V, S, B, lam=10.0, E=EMBED_DIM, g_state=None, d_state=None, dtype=torch.float32, reducer=None,
-                 G=None, D=None, overlap_streams=False, head_side_stream=False):
+                 G=None, D=None, overlap_streams=False, head_side_stream=None):
         self.K, self.V, self.S, self.B, self.lam = K, V, S, B, float(lam)
         self.G = G if G is not None else Network(K, "G", V, S, B, E, dtype=dtype, state_dict=g_state)
         self.D = D if D is not None else Network(K, "D", V, S, B, E, dtype=dtype, state_dict=d_state)
@@ -116,10 +116,15 @@ class GanStep:
             # backward: filter gradients beside the dgrad -> LayerNorm-backward chain (trunk.enable_wgrad_overlap)
             self.G.trunk.enable_wgrad_overlap(self.side)
             self.D.trunk.enable_wgrad_overlap(self.side)
-        # The recurrent heads are chains of short dependent launches; everything off the chain (embedding / decoder products,
-        # every parameter-gradient GEMM) can run on a stream of its own beside it (head.py; bit-identical results).  Measured:
-        # 47.30 / 47.37 ms per step with it against 47.37 / 47.19 without (same box) - the per-step fork / join events cost what
-        # the overlap of 5-15 us kernels returns - so it is OFF by default (bench.py --head-side-stream).
+        # The recurrent heads are chains of short dependent launches.  Their parameter-gradient work (95 of the ~330 launches per step:
+        # every weight-gradient GEMM and column sum) is off that chain: with a stream of its own the backward pass DEFERS it there
+        # behind one fork per pass (head.py; bit-identical results), and nothing waits for it until head.join() in front of the
+        # optimiser - the chain, and the encoder backward after it, no longer carry those launches: 44.32 / 44.32 / 44.39 against
+        # 45.12 / 45.01 / 45.20 ms per step (same box, interleaved; profiles/r04_head_deferred_grads_ab.log).  Part of the two-stream
+        # schedule by default (head_side_stream=None follows overlap_streams).  Round 3's form - a fork per time step and a join at
+        # the end of every pass - measured equal to none.
+        if head_side_stream is None:
+            head_side_stream = overlap_streams
         self.head_side = torch.cuda.Stream(device=dev) if (head_side_stream and dev.type == "cuda") else None
         self.G.head.enable_side_stream(self.head_side)
         self.D.head.enable_side_stream(self.head_side)

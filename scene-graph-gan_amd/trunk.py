@@ -249,7 +249,15 @@ class Trunk:
         n = len(self.layers)
         for j, lay in enumerate(self.layers):
             lay["a_s16"] = lay["dy_s16"] = False
-            if not on or not lay["has_ln"]:
+            if not on:
+                continue
+            if not lay["has_ln"]:
+                # the last convolution: its dy is the head's f32 gradient, converted once per backward (sgg_presplit16) where both of
+                # its consumers take pre-split operands and its input activation arrives pre-split as well
+                wg = K.wgrad_resident(lay["out_shape"][0], lay["out_shape"][1], lay["out_shape"][2], lay["cin"], lay["cout"], lay["k"], lay["s"])
+                lay["dy_s16"] = (j == n - 1 and j > 0 and hasattr(K, "presplit16") and bool(getattr(K, "presplit_head_grad", True)) and
+                                 lay["ws_bwd"] is not None and
+                                 lay["ws_layout_bwd"] in (1, 2, 3, 4) and wg and lay["cout"] % 32 == 0)
                 continue
             B, ho, wo, cout = lay["out_shape"]
             wg_ok = lambda l: K.wgrad_resident(B, l["out_shape"][1], l["out_shape"][2], l["cin"], l["cout"], l["k"], l["s"])
@@ -393,13 +401,21 @@ class Trunk:
         main = torch.cuda.current_stream() if side is not None else None
         dybufs = [self._dY, self._dY2] if side is not None else [self._dY]
         reader_done = [None] * len(dybufs)        # event: the wgrad that reads this dY buffer has finished
+        dy_s16 = False                             # dy is pre-split (written so by the LayerNorm backward of this layer)
+        dy_f32 = dy                                # (the last convolution's bias gradient sums the f32 tensor)
         if f16:
             K.fill(self.amax[1], 0.0)
             K.absmax(dy, self._am(1, n - 1))
             if any(l.get("dy_s16") for l in self.layers):
                 K.fill(self.pq, 0.0)
+            if self.layers[-1].get("dy_s16") and self.layers[-1].get("ws_mode") == getattr(K, "conv_precision", 0):
+                # no LayerNorm kernel writes the head's gradient: one conversion pass, and the last layer's dgrad and filter gradient
+                # stage it by DMA like every other layer's
+                if getattr(self, "_dctx16", None) is None:
+                    self._dctx16 = torch.empty_like(dy)
+                K.presplit16(dy, self._dctx16, self._am(1, n - 1))
+                dy, dy_s16 = self._dctx16, True
         cur = -1                                   # dY buffer holding dy (-1: the caller's dctx)
-        dy_s16 = False                             # dy is pre-split (written so by the LayerNorm backward of this layer)
         for j in range(n - 1, -1, -1):
             lay = self.layers[j]
             prv = self.layers[j - 1] if j else None
@@ -429,7 +445,7 @@ class Trunk:
                         reader_done[cur].record(side)
             if not lay["has_ln"]:
                 # last conv: BiasAddGrad = column sums of dy (LN layers get theirs from ln_elu_bwd below)
-                K.colsum(dy.view(-1, lay["cout"]), lay["gb"], False)
+                K.colsum(dy_f32.view(-1, lay["cout"]), lay["gb"], False)
             if j == 0:
                 break
             prev = self.layers[j - 1]

@@ -118,6 +118,28 @@ def _weights(hip, Ci, Co, k, lay_f, lay_b, seed):
     return w, wf, am, ws_f, ws_b
 
 
+@pytest.mark.parametrize("shape", [(2, 14, 14, 512), (3, 5, 7, 32), (1, 1, 1, 96)])
+def test_presplit16_conversion_is_the_split(mode2, shape):
+    """sgg_presplit16: an f32 tensor that no LayerNorm kernel produces (the head's gradient w.r.t. `downsampled`) -> the same
+    pre-split format, bit for bit f16_split2 under the scale of the amax word (a maximum or a bound); also in place."""
+    hip = mode2
+    x = rnd(shape, 41, 3.0)
+    x[0, 0, 0, 0] = 17.0
+    bits = lambda t: t.contiguous().view(torch.int32)
+    am = torch.zeros(1, device="cuda")
+    xd = x.cuda()
+    hip.absmax(xd, am)
+    assert float(am) == float(x.abs().max())
+    out = torch.full(shape, float("nan"), device="cuda")
+    hip.presplit16(xd, out, am)
+    assert torch.equal(bits(out.cpu()), bits(to_s16(x, float(am))))
+    hip.presplit16(xd, xd, am)                                    # in place
+    assert torch.equal(bits(xd), bits(out))
+    bound = torch.tensor([2.7 * float(am)], device="cuda")        # a bound instead of the maximum: another scale, same rule
+    hip.presplit16(x.cuda(), out, bound)
+    assert torch.equal(bits(out.cpu()), bits(to_s16(x, 2.7 * float(am))))
+
+
 FWD_CASES = [
     # B, H, W, Cin, Cout, k, stride      (the resident kernel families)
     (3, 16, 24, 32, 32, 3, 1),       # four-wave 3x3, 32-column tiling (two-wave workgroups)
@@ -130,8 +152,9 @@ FWD_CASES = [
     (2, 16, 16, 128, 128, 5, 2),     # band-resident 5x5 stride 2 (layout 2)
     (2, 16, 16, 256, 512, 5, 2),
     (4, 8, 8, 512, 512, 5, 2),       # few work items: channel chunks split over two workgroups
-    (2, 64, 64, 128, 256, 5, 2),     # 256 output columns: eight-wave workgroups (one patch per 256 columns), 9.1 bands
-    (2, 32, 32, 256, 512, 5, 2),     # ... two of them per band forward, one in the dgrad direction; bands cross the image boundary
+    # 256+ output columns and more than 128 (band, 256-column) items: eight-wave workgroups, one patch per 256 columns
+    (10, 112, 112, 256, 256, 5, 2),  # 56 x 56 grid: 140 bands, wide in both directions
+    (5, 112, 112, 128, 512, 5, 2),   # 70 bands x two 256-column tiles forward; 128 columns in the dgrad direction
 ]
 
 
