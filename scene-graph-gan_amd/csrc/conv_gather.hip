@@ -14,6 +14,7 @@
 // staged global -> registers -> LDS (KC layout, see mma_f32.h) with the next slab's global loads in flight
 // while the current slab is contracted (register prefetch, one LDS buffer).
 #include "split16.h"
+#include "mma_f32.h"
 #include "conv_halo.h"
 #include <stdlib.h>
 
@@ -552,33 +553,38 @@ __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) voi
 
 // ---------------------------------------------------------------------------------------------------
 // Cin = 3 forward (conv1_1, generator_with_attention.py:29): K = 27, HBM-bound on the 32-channel output.
-// 8 lanes per output pixel, 4 output channels each -> a wave stores 1 KiB contiguous per instruction.
-// Weights are HWIO [3][3][3][Cout] read through LDS.
+// Weights are HWIO [3][3][3][Cout].
 // ---------------------------------------------------------------------------------------------------
-// Tile = 8 rows x 32 columns of output pixels; thread = (column, 4 output channels).  The zero-padded 10 x 34 input
-// patch sits in LDS as [row][col][4] (x, y, z, 0: 16-B pixels -> aligned ds_read_b128); a thread walks its column
-// downwards with a rolling 3-row window (3 new LDS reads per pixel) and its 27 x 4 weights in registers: 108 FMAs,
-// 3 LDS reads and one 16-B store per pixel (the previous kernel issued ~250 instructions per pixel and ran at 1.7 TB/s).
-// Sum order per output: bias, then (kh, kw, ci) ascending - the fmaf chain of the reference order.
-// tile_stats (optional): (count, mean, M2) of the tile's outputs for the following LayerNorm, [B][tiles_y * tiles_x][3].
-__global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// Tile = 8 rows x 32 columns of output pixels.  The zero-padded 10 x 34 input patch sits in LDS as three channel PLANES
+// [ci][row][pitch 36]; a wave owns two rows of the tile = two 32-pixel MFMA row tiles and contracts K = 27 (+ 1 zero) with
+// fourteen v_mfma_f32_32x32x2_f32 per row tile: A[pixel][k = 2 s + h] is ONE conflict-free ds_read_b32 (32 consecutive floats
+// per half-wave) at a per-lane tap offset, B[k][output channel] fourteen registers loaded once per workgroup.  28 MFMAs of 64
+// cycles per wave and tile = 1792 cycles where the VALU form of rounds 1 - 3 (108 FMAs per pixel and 4 output channels, a rolling
+// 3-row window) took 3456: the kernel was VALU-bound at 0.42 of the HBM peak (135 us), and is HBM-bound now.
+// Sum order per output: bias, then (kh, kw, ci) ascending - the f32 MFMA is an exact, k-ordered fmaf chain (mma_f32.h), so the
+// results are those of the VALU form bit for bit.
+// tile_stats (optional): (count, mean, M2, max dev) of the tile's outputs for the following LayerNorm, [B][tiles_y * tiles_x][4].
+__global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ tile_stats, int H, int W, int pt, int pl,
                                                           int tiles_x, int tiles_y, int ntiles) {
-  constexpr int COUT = 32;
-  __shared__ __attribute__((aligned(16))) f32x4 patch[10 * 34];
+  constexpr int COUT = 32, PITCH = 36, PLANE = 10 * PITCH;
+  __shared__ float patch[3 * PLANE];
   __shared__ float red[12];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = tid & 7, col = tid >> 3;
-  // the 27 x 4 weights of this thread's output channels stay in registers for every tile the workgroup walks (one workgroup per
-  // tile re-read 110 KB of weights per 32 KB of output)
-  f32x4 wv[27];
+  const int i = lane & 31, h = lane >> 5;
+  // B operand (this lane: output channel i, k = 2 s + h) and the patch offset of tap k = (kh * 3 + kw) * 3 + ci, for every tile
+  float wb[14];
+  int aoff[14];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w + k * COUT + sub * 4);
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + sub * 4);
-  // the patch of the NEXT tile is fetched into registers while this tile is computed (two pixels per thread): with the loads issued
-  // between the two barriers their whole latency was exposed once per tile (two resident workgroups per CU cannot hide it)
-  f32x4 pv[2];
+  for (int s = 0; s < 14; ++s) {
+    const int k = 2 * s + h;
+    wb[s] = k < 27 ? w[k * COUT + i] : 0.f;
+    aoff[s] = k < 27 ? (k % 3) * PLANE + (k / 9) * PITCH + (k / 3) % 3 : 0;
+  }
+  const float bv = bias[i];
+  // the patch of the NEXT tile is fetched into registers while this tile is computed (two pixels per thread)
+  float pv[2][3];
   auto load_patch = [&](int tile_) __attribute__((always_inline)) {
     const int tx_ = tile_ % tiles_x, t2_ = tile_ / tiles_x;
     const int ty_ = t2_ % tiles_y, b_ = t2_ / tiles_y;
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restric
       const int idx = tid + 256 * k;
       const int r = idx / 34, c = idx % 34;
       const int yy = ty_ * 8 - pt + r, xx = tx_ * 32 - pl + c;
-      pv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pv[k][0] = pv[k][1] = pv[k][2] = 0.f;
       if (tile_ < ntiles && idx < 10 * 34 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
         const float* px = x + ((size_t)(b_ * H + yy) * W + xx) * 3;
         pv[k][0] = px[0]; pv[k][1] = px[1]; pv[k][2] = px[2];
@@ -600,51 +606,71 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const float* __restric
   const int ty = t2 % tiles_y, b = t2 / tiles_y;
   const int y0 = ty * 8, x0 = tx * 32;
   __syncthreads();            // the previous tile's patch / reduction scratch are free
-  patch[tid] = pv[0];
-  if (tid + 256 < 10 * 34) patch[tid + 256] = pv[1];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < 10 * 34) {
+      const int o = (idx / 34) * PITCH + idx % 34;
+      patch[o] = pv[k][0];
+      patch[PLANE + o] = pv[k][1];
+      patch[2 * PLANE + o] = pv[k][2];
+    }
+  }
   __syncthreads();
   load_patch(tile + gridDim.x);
 
-  f32x4 rows[3][3];
+  // rows 2 wave, 2 wave + 1 of the tile; accumulator register r of lane (i, h): pixel column acc_row(r, lane), output channel i
+  f32x16 out[2];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) rows[r][kw] = patch[r * 34 + col + kw];
-  f32x4 out[8];
-  const bool col_ok = x0 + col < W;
+    for (int r = 0; r < 16; ++r) out[m][r] = bv;
+  const float* prow = patch + 2 * wave * PITCH + i;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) rows[(r + 2) % 3][kw] = patch[(r + 2) * 34 + col + kw];
-    f32x4 acc = bv;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) acc += rows[(r + kh) % 3][kw][ci] * wv[(kh * 3 + kw) * 3 + ci];
-    out[r] = acc;
-    if (col_ok && y0 + r < H) *reinterpret_cast<f32x4*>(y + ((size_t)(b * H + y0 + r) * W + x0 + col) * COUT + sub * 4) = acc;
+  for (int s = 0; s < 14; ++s) {
+    out[0] = mfma32(prow[aoff[s]], wb[s], out[0]);
+    out[1] = mfma32(prow[aoff[s] + PITCH], wb[s], out[1]);
   }
+  // 16-byte stores through the in-register quad transpose (sgg_common.h): afterwards lane (h, g = i >> 2, k = i & 3) holds pixel
+  // column 8 q + 4 h + k and output channels 4 g .. 4 g + 3 (64 four-byte stores per wave and tile are bound by the CU's store
+  // issue rate, not by bandwidth)
+  const bool full = y0 + 8 <= H && x0 + 32 <= W;       // (uniform; edge tiles mask per element)
+  const int cmax = W - x0 - 4 * h;                      // column offsets 8 q + (0 .. 3) below this are inside the image
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int yy = y0 + 2 * wave + m;
+    float* ybase = y + ((size_t)(b * H + yy) * W + x0 + 4 * h + (i & 3)) * COUT + (i & ~3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v0 = out[m][4 * q], v1 = out[m][4 * q + 1], v2 = out[m][4 * q + 2], v3 = out[m][4 * q + 3];
+      sgg_quad_transpose4(v0, v1, v2, v3, lane);
+      if (full || (yy < H && 8 * q + (i & 3) < cmax)) sgg_out_store4(ybase + 8 * q * COUT, f32x4{v0, v1, v2, v3});
+    }
+  }
+  auto ok = [&](int m, int r) { return full || (y0 + 2 * wave + m < H && (r & 3) + 8 * (r >> 2) < cmax); };
   if (tile_stats) {
     const int rows_ok = min(8, H - y0), cols_ok = min(32, W - x0);
     const float cnt = (float)(rows_ok * cols_ok * COUT);
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (col_ok && y0 + r < H) s += (out[r][0] + out[r][1]) + (out[r][2] + out[r][3]);
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok(m, r)) s += out[m][r];
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const float mean_t = (red[0] + red[1] + red[2] + red[3]) / cnt;
     float q = 0.f, dm = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (col_ok && y0 + r < H) {
-        const f32x4 d = out[r] - mean_t;
-        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-        dm = fmaxf(fmaxf(dm, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
-      }
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok(m, r)) {
+          const float d = out[m][r] - mean_t;
+          q += d * d;
+          dm = fmaxf(dm, fabsf(d));
+        }
     q = wave_sum(q);
     dm = wave_max(dm);
     if (lane == 0) { red[4 + wave] = q; red[8 + wave] = dm; }

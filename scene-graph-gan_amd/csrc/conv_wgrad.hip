@@ -476,27 +476,31 @@ static void launch_slab_reduce(const float* slabs, float* out, long long n4, int
 
 // ---------------------------------------------------------------------------------------------------
 // Cin = 3 (conv1_1): dW[27][32] over up to 3.2 M pixels; HBM-bound on dy (411 MB at batch 64 / 224^2).
-// Same decomposition as conv_c3_fwd_kernel: tile = 8 rows x 32 columns, thread = (column, 4 output channels); the
-// zero-padded 10 x 34 input patch sits in LDS as 16-B pixels, a thread walks its column with a rolling 3-row window and
-// accumulates its 27 x 4 partial sums in registers over all tiles of the workgroup (one coalesced 16-B dy load,
-// 3 LDS reads and 108 FMAs per pixel); one shuffle/LDS reduction per workgroup at the end, then the deterministic
-// slab reduce.
+// Same tiling as conv_c3_fwd_kernel (8 rows x 32 columns, the zero-padded 10 x 34 input patch in LDS as three channel planes of
+// pitch 36); a wave owns two rows = 64 pixels and contracts them with 32 v_mfma_f32_32x32x2_f32 into ONE 32 x 32 accumulator tile
+// dW[tap k][output channel] (16 registers, kept over all tiles of the workgroup): A[k][pixel] is a conflict-free ds_read_b32 at a
+// per-lane tap offset (the 27 offsets fall into 27 different banks), B[pixel][channel] the wave's dy values - fetched a tile ahead
+// with 16-byte loads and brought into the operand layout by the in-register quad transpose (sgg_common.h).  2048 MFMA cycles per wave and tile where the VALU form of rounds 1 - 3
+// (108 FMAs per pixel and 4 channels) took 3456.  One LDS reduction of the four waves per workgroup at the end, then the
+// deterministic slab reduce.  Sums: pixels in tile order per wave (exact f32 fmaf chains, mma_f32.h).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ slabs, int H, int W, int pt, int pl,
-                                                            int tiles_x, int tiles_y, int ntiles, int tiles_per_wg) {
-  constexpr int COUT = 32;
-  __shared__ __attribute__((aligned(16))) f32x4 patch[10 * 34];
-  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 27 * 8];
+__global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ slabs, int H, int W, int pt, int pl,
+                                                               int tiles_x, int tiles_y, int ntiles, int tiles_per_wg) {
+  constexpr int COUT = 32, PITCH = 36, PLANE = 10 * PITCH;
+  __shared__ float patch[3 * PLANE];
+  __shared__ float red[4 * 32 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = tid & 7, col = tid >> 3;
-  f32x4 acc[27];
+  const int i = lane & 31, h = lane >> 5;
+  // A operand of this lane: tap k = i = (kh * 3 + kw) * 3 + ci (rows 27 .. 31 of the tile are never stored: any finite value)
+  const int kk = i < 27 ? i : 0;
+  const int abase = (kk % 3) * PLANE + (kk / 9) * PITCH + (kk / 3) % 3 + 2 * wave * PITCH + 4 * h;
+  f32x16 acc;
 #pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
-  // the NEXT tile's patch pixels and dy vectors are fetched into registers while this tile is computed (conv_c3_fwd_kernel): the
-  // loads sat between the two barriers of a tile, their latency exposed once per tile
-  f32x4 pv[2], dvn[8];
+  // the NEXT tile's patch pixels and this wave's dy values are fetched into registers while this tile is computed
+  float pv[2][3], dvn[2][16];
   auto load_tile = [&](int t_) __attribute__((always_inline)) {
     const int tx_ = t_ % tiles_x, t2_ = t_ / tiles_x;
     const int ty_ = t2_ % tiles_y, b_ = t2_ / tiles_y;
@@ -507,69 +511,64 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const float* __restr
       const int idx = tid + 256 * k;
       const int r = idx / 34, c = idx % 34;
       const int yy = y0_ - pt + r, xx = x0_ - pl + c;
-      pv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pv[k][0] = pv[k][1] = pv[k][2] = 0.f;
       if (live && idx < 10 * 34 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
         const float* px = x + ((size_t)(b_ * H + yy) * W + xx) * 3;
         pv[k][0] = px[0]; pv[k][1] = px[1]; pv[k][2] = px[2];
       }
     }
-    // this thread's 8 dy vectors (zeros outside the image: they contribute nothing)
-    const bool col_ok = live && x0_ + col < W;
+    // 16-byte loads: lane (h, g = i >> 2, k = i & 3) fetches dy of pixel (row 2 wave + m, column 8 q + 4 h + k), channels 4 g .. 4 g + 3
+    // (zeros outside the image: they contribute nothing); the quad transpose at the point of use turns them into this lane's
+    // channel i at columns 8 q + 4 h + (0 .. 3) - the B operands of MFMAs (q, j), whose two pixels are columns 8 q + j and 8 q + 4 + j
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      dvn[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (col_ok && y0_ + r < H) dvn[r] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(b_ * H + y0_ + r) * W + x0_ + col) * COUT + sub * 4);
+    for (int m = 0; m < 2; ++m) {
+      const int yy = y0_ + 2 * wave + m;
+      const float* drow = dy + ((size_t)(b_ * H + yy) * W + x0_ + 4 * h + (i & 3)) * COUT + (i & ~3);
+      const int cmax = W - x0_ - 4 * h - (i & 3);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live && yy < H && 8 * q < cmax) v = *reinterpret_cast<const f32x4*>(drow + (size_t)(8 * q) * COUT);
+        dvn[m][4 * q] = v[0]; dvn[m][4 * q + 1] = v[1]; dvn[m][4 * q + 2] = v[2]; dvn[m][4 * q + 3] = v[3];
+      }
     }
   };
   load_tile(t_begin);
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
-    patch[tid] = pv[0];
-    if (tid + 256 < 10 * 34) patch[tid + 256] = pv[1];
-    f32x4 dv[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) dv[r] = dvn[r];
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < 10 * 34) {
+        const int o = (idx / 34) * PITCH + idx % 34;
+        patch[o] = pv[k][0];
+        patch[PLANE + o] = pv[k][1];
+        patch[2 * PLANE + o] = pv[k][2];
+      }
+    }
+    float dv[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        dv[m][4 * q] = dvn[m][4 * q]; dv[m][4 * q + 1] = dvn[m][4 * q + 1]; dv[m][4 * q + 2] = dvn[m][4 * q + 2]; dv[m][4 * q + 3] = dvn[m][4 * q + 3];
+        sgg_quad_transpose4(dv[m][4 * q], dv[m][4 * q + 1], dv[m][4 * q + 2], dv[m][4 * q + 3], lane);
+      }
     __syncthreads();
     load_tile(t + 1);
-    f32x4 rows[3][3];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) rows[r][kw] = patch[r * 34 + col + kw];
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) rows[(r + 2) % 3][kw] = patch[(r + 2) * 34 + col + kw];
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-          for (int ci = 0; ci < 3; ++ci) acc[(kh * 3 + kw) * 3 + ci] += rows[(r + kh) % 3][kw][ci] * dv[r];
-    }
+        for (int j = 0; j < 4; ++j) acc = mfma32(patch[abase + m * PITCH + 8 * q + j], dv[m][4 * q + j], acc);
   }
-  // lanes with equal `sub` (stride 8) hold partial sums of the same 4 channels: combine the wave's 8 columns, then the 4 waves
+  // the four waves' tiles -> one [27][32] slab of the workgroup (register r of lane (i, h): tap acc_row(r, lane), channel i)
 #pragma unroll
-  for (int k = 0; k < 27; ++k) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float v = acc[k][c];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      acc[k][c] = v;
-    }
-  }
+  for (int r = 0; r < 16; ++r) red[(wave * 32 + acc_row(r, lane)) * 32 + i] = acc[r];
   __syncthreads();
-  if (lane < 8) {
-#pragma unroll
-    for (int k = 0; k < 27; ++k) red[(wave * 27 + k) * 8 + lane] = acc[k];
-  }
-  __syncthreads();
-  if (tid < 27 * 8) {
-    const f32x4 v = (red[tid] + red[27 * 8 + tid]) + (red[2 * 27 * 8 + tid] + red[3 * 27 * 8 + tid]);
-    reinterpret_cast<f32x4*>(slabs + (size_t)blockIdx.x * 27 * COUT)[tid] = v;     // [k][sub*4..] == [27][32]
-  }
+  for (int e = tid; e < 27 * COUT; e += 256)
+    slabs[(size_t)blockIdx.x * 27 * COUT + e] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -157,6 +157,11 @@ DEFAULT_OPTIONS = {
     # True (with presplit): the gradient the attention head hands to the last convolution is converted to the pre-split format once
     # per backward (sgg_presplit16), so that `downsampled`'s dgrad and filter gradient stage it by DMA as well
     "presplit_head_grad": True,
+    # two-stream schedule: True = the filter gradient of layer j starts when dgrad_j has finished (beside the LayerNorm backward of
+    # layer j - 1) instead of together with dgrad_j (trunk.backward)
+    "wgrad_late": True,
+    # two-stream schedule: HIP priority of the side streams (0 = default; positive = lower than the main stream's, negative = higher)
+    "side_priority": 0,
     # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward /
     # never fuse in passes with backward
     "ln_fusion_skip": (),

@@ -111,7 +111,9 @@ class GanStep:
         # the MFMA-bound convolutions of the other, launch tails are filled).  Measured +3 % triples/s; off by
         # default because concurrent kernels make per-kernel durations (the roofline measurement) meaningless.
         self._g_reuse, self._g_reuse_armed = None, False       # (images, ctx) of G's encoder within one train_iteration
-        self.side = torch.cuda.Stream(device=dev) if (overlap_streams and dev.type == "cuda") else None
+        # (option side_priority: priority of the side streams - everything on them is off the critical chain of the main stream)
+        prio = int(getattr(K, "side_priority", 0))
+        self.side = torch.cuda.Stream(device=dev, priority=prio) if (overlap_streams and dev.type == "cuda") else None
         if self.side is not None:
             # backward: filter gradients beside the dgrad -> LayerNorm-backward chain (trunk.enable_wgrad_overlap)
             self.G.trunk.enable_wgrad_overlap(self.side)
@@ -125,7 +127,7 @@ class GanStep:
         # the end of every pass - measured equal to none.
         if head_side_stream is None:
             head_side_stream = overlap_streams
-        self.head_side = torch.cuda.Stream(device=dev) if (head_side_stream and dev.type == "cuda") else None
+        self.head_side = torch.cuda.Stream(device=dev, priority=prio) if (head_side_stream and dev.type == "cuda") else None
         self.G.head.enable_side_stream(self.head_side)
         self.D.head.enable_side_stream(self.head_side)
 

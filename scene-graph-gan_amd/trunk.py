@@ -434,15 +434,18 @@ class Trunk:
                         K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
                     else:
                         K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
-            if side is None:
-                wgrad()
-            else:
-                side.wait_stream(main)            # dy_j (and its amax word) are complete
+            def wgrad_on_side(cur=cur):
                 with torch.cuda.stream(side):
                     wgrad()
                     if cur >= 0:
                         reader_done[cur] = torch.cuda.Event()
                         reader_done[cur].record(side)
+            late = side is not None and j > 0 and bool(getattr(K, "wgrad_late", False))
+            if side is None:
+                wgrad()
+            elif not late:
+                side.wait_stream(main)            # dy_j (and its amax word) are complete
+                wgrad_on_side()
             if not lay["has_ln"]:
                 # last conv: BiasAddGrad = column sums of dy (LN layers get theirs from ln_elu_bwd below)
                 K.colsum(dy_f32.view(-1, lay["cout"]), lay["gb"], False)
@@ -464,6 +467,13 @@ class Trunk:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"] if ws is not None else 0)
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])
+            if late:
+                # option wgrad_late: the filter gradient starts when dgrad_j has FINISHED, i.e. beside the HBM-bound LayerNorm backward
+                # of layer j - 1 instead of beside dgrad_j (both MFMA-bound)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                wgrad_on_side()
             nxt_s16 = bool(prev.get("dy_s16")) and prev.get("ws_mode") == getattr(K, "conv_precision", 0) and self._ln_fin is not None
             if nxt_s16:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, None, None, None, self._am(1, j - 1),

@@ -3,7 +3,7 @@
 set -e
 TAG=$1; shift
 mkdir -p gpurun_out/$TAG
-for rep in 1 2 3; do
+for rep in 1 2; do
   i=0
   for v in "$@"; do
     i=$((i+1))

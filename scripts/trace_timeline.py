@@ -1,0 +1,63 @@
+"""Where a two-stream step spends its time: python scripts/trace_timeline.py <kernel_trace.csv> [n_last_steps]
+(rocprofv3 --kernel-trace --output-format csv of `bench.py --steps N ...`).  Kernels are classed as MFMA-bound convolution work or
+"other" (LayerNorm, heads, optimiser, ...); the union of their [start, end) intervals over the last steps of the trace gives the time
+with a matrix kernel resident, with only other kernels resident, and with nothing resident, and the kernels that fill the
+matrix-idle time."""
+import csv
+import sys
+from collections import defaultdict
+
+path = sys.argv[1]
+rows = []
+for r in csv.DictReader(open(path)):
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
+rows.sort()
+mfma = lambda n: n.startswith("void conv_") and "c3" not in n and "slab_reduce" not in n
+# the timed window: from the first Adam launch of the last `nsteps` steps ... simply the last fraction of the trace by Adam launches
+adam = [i for i, r in enumerate(rows) if r[2].startswith("adam_kernel")]
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+lo = rows[adam[-2 * nsteps - 1]][1] if len(adam) > 2 * nsteps else rows[0][0]
+hi = rows[adam[-1]][1]
+win = [r for r in rows if r[0] >= lo and r[1] <= hi]
+
+
+def union(iv):
+    iv = sorted(iv)
+    out = []
+    for a, b in iv:
+        if out and a <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+    return out
+
+
+def length(u):
+    return sum(b - a for a, b in u)
+
+
+um = union([(a, b) for a, b, n, q in win if mfma(n)])
+ua = union([(a, b) for a, b, n, q in win])
+total = hi - lo
+print("window %.2f ms = %d steps of %.2f ms; kernels %d, queues %s" % (total / 1e6, nsteps, total / 1e6 / nsteps, len(win), sorted({q for *_, q in win})))
+print("  a matrix (conv) kernel resident : %6.2f ms per step" % (length(um) / 1e6 / nsteps))
+print("  only other kernels resident     : %6.2f ms per step" % ((length(ua) - length(um)) / 1e6 / nsteps))
+print("  nothing resident                : %6.2f ms per step" % ((total - length(ua)) / 1e6 / nsteps))
+# who runs while no matrix kernel is resident
+acc = defaultdict(float)
+j = 0
+for a, b, n, q in win:
+    if mfma(n):
+        continue
+    # part of [a, b) outside um
+    out = b - a
+    for c, d in um:
+        if d <= a:
+            continue
+        if c >= b:
+            break
+        out -= min(b, d) - max(a, c)
+    acc[n.split("(")[0][:70]] += max(out, 0)
+print("  kernels resident while no matrix kernel is (ms per step, summed per kernel; overlapping each other is counted twice):")
+for n, v in sorted(acc.items(), key=lambda kv: -kv[1])[:25]:
+    print("    %-72s %6.3f" % (n, v / 1e6 / nsteps))
