@@ -563,24 +563,31 @@ __global__ __launch_bounds__(256, (P == 2 && BK == 32 && BN <= 128 ? 3 : 2)) voi
 // 3-row window) took 3456: the kernel was VALU-bound at 0.42 of the HBM peak (135 us), and is HBM-bound now.
 // Sum order per output: bias, then (kh, kw, ci) ascending - the f32 MFMA is an exact, k-ordered fmaf chain (mma_f32.h), so the
 // results are those of the VALU form bit for bit.
-// tile_stats (optional): (count, mean, M2, max dev) of the tile's outputs for the following LayerNorm, [B][tiles_y * tiles_x][4].
+// tile_stats (optional): (count, mean, M2, max dev) of every wave's two rows of a tile for the following LayerNorm,
+// [B][tiles_y * tiles_x * 4][4].
+// workgroup barrier that orders LDS accesses only (no wait for outstanding global loads / stores)
+__device__ __forceinline__ void c3_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// patch offset of tap k = (kh * 3 + kw) * 3 + ci in the planar 10 x 36 image (k = 27: the zero column of the contraction)
+__host__ __device__ constexpr int c3_tap_off(int k) { return k < 27 ? (k % 3) * 360 + (k / 9) * 36 + (k / 3) % 3 : 0; }
+
 __global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ tile_stats, int H, int W, int pt, int pl,
                                                           int tiles_x, int tiles_y, int ntiles) {
   constexpr int COUT = 32, PITCH = 36, PLANE = 10 * PITCH;
   __shared__ float patch[3 * PLANE];
-  __shared__ float red[12];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  // B operand (this lane: output channel i, k = 2 s + h) and the patch offset of tap k = (kh * 3 + kw) * 3 + ci, for every tile
+  // B operand (this lane: output channel i, k = 2 s + h), for every tile
   float wb[14];
-  int aoff[14];
 #pragma unroll
   for (int s = 0; s < 14; ++s) {
     const int k = 2 * s + h;
     wb[s] = k < 27 ? w[k * COUT + i] : 0.f;
-    aoff[s] = k < 27 ? (k % 3) * PLANE + (k / 9) * PITCH + (k / 3) % 3 : 0;
   }
   const float bv = bias[i];
   // the patch of the NEXT tile is fetched into registers while this tile is computed (two pixels per thread)
@@ -605,7 +612,8 @@ __global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __rest
   const int tx = tile % tiles_x, t2 = tile / tiles_x;
   const int ty = t2 % tiles_y, b = t2 / tiles_y;
   const int y0 = ty * 8, x0 = tx * 32;
-  __syncthreads();            // the previous tile's patch / reduction scratch are free
+  // (raw barriers with an LDS-only wait: __syncthreads() also drains vmcnt, i.e. waits for the previous tile's output stores)
+  c3_lds_barrier();            // the previous tile's patch is free
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int idx = tid + 256 * k;
@@ -616,7 +624,7 @@ __global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __rest
       patch[2 * PLANE + o] = pv[k][2];
     }
   }
-  __syncthreads();
+  c3_lds_barrier();
   load_patch(tile + gridDim.x);
 
   // rows 2 wave, 2 wave + 1 of the tile; accumulator register r of lane (i, h): pixel column acc_row(r, lane), output channel i
@@ -626,14 +634,19 @@ __global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[m][r] = bv;
   const float* prow = patch + 2 * wave * PITCH + i;
+#ifndef C3_ABL_NOMFMA      // (timing-only ablations, wrong results: -DC3_ABL_NOMFMA no contraction, -DC3_ABL_NOSTORE no output stores)
 #pragma unroll
   for (int s = 0; s < 14; ++s) {
-    out[0] = mfma32(prow[aoff[s]], wb[s], out[0]);
-    out[1] = mfma32(prow[aoff[s] + PITCH], wb[s], out[1]);
+    const int ao = h ? c3_tap_off(2 * s + 1) : c3_tap_off(2 * s);
+    out[0] = mfma32(prow[ao], wb[s], out[0]);
+    out[1] = mfma32(prow[ao + PITCH], wb[s], out[1]);
   }
+#else
+  out[0][0] += prow[0];
+  out[1][0] += prow[PITCH];
+#endif
   // 16-byte stores through the in-register quad transpose (sgg_common.h): afterwards lane (h, g = i >> 2, k = i & 3) holds pixel
-  // column 8 q + 4 h + k and output channels 4 g .. 4 g + 3 (64 four-byte stores per wave and tile are bound by the CU's store
-  // issue rate, not by bandwidth)
+  // column 8 q + 4 h + k and output channels 4 g .. 4 g + 3
   const bool full = y0 + 8 <= H && x0 + 32 <= W;       // (uniform; edge tiles mask per element)
   const int cmax = W - x0 - 4 * h;                      // column offsets 8 q + (0 .. 3) below this are inside the image
 #pragma unroll
@@ -644,43 +657,50 @@ __global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __rest
     for (int q = 0; q < 4; ++q) {
       float v0 = out[m][4 * q], v1 = out[m][4 * q + 1], v2 = out[m][4 * q + 2], v3 = out[m][4 * q + 3];
       sgg_quad_transpose4(v0, v1, v2, v3, lane);
+#ifdef C3_ABL_NOSTORE
+      if (v0 == 12345.678f)
+#endif
       if (full || (yy < H && 8 * q + (i & 3) < cmax)) sgg_out_store4(ybase + 8 * q * COUT, f32x4{v0, v1, v2, v3});
     }
   }
-  auto ok = [&](int m, int r) { return full || (y0 + 2 * wave + m < H && (r & 3) + 8 * (r >> 2) < cmax); };
   if (tile_stats) {
-    const int rows_ok = min(8, H - y0), cols_ok = min(32, W - x0);
+    // one record per WAVE (its two rows of the tile): no workgroup reduction, no barrier.  (Measured alone at batch 64: 90 us
+    // without the partials, 109 - 114 us with them in this form, 125 us with one record per tile - two barriers and an LDS
+    // reduction -, 122 us with one record per row.)
+    const int rows_ok = max(0, min(2, H - (y0 + 2 * wave))), cols_ok = min(32, W - x0);
     const float cnt = (float)(rows_ok * cols_ok * COUT);
-    float s = 0.f;
+    auto ok = [&](int m, int r) { return y0 + 2 * wave + m < H && (r & 3) + 8 * (r >> 2) < cmax; };
+    float sm = 0.f;
+    if (full) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 16; ++r) sm += out[0][r] + out[1][r];
+    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (ok(m, r)) s += out[m][r];
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    const float mean_t = (red[0] + red[1] + red[2] + red[3]) / cnt;
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok(m, r)) sm += out[m][r];
+    }
+    sm = wave_sum_dpp(sm);
+    const float mean_w = cnt > 0.f ? sm / cnt : 0.f;
     float q = 0.f, dm = 0.f;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (ok(m, r)) {
-          const float d = out[m][r] - mean_t;
+        if (full || ok(m, r)) {
+          const float d = out[m][r] - mean_w;
           q += d * d;
           dm = fmaxf(dm, fabsf(d));
         }
-    q = wave_sum(q);
-    dm = wave_max(dm);
-    if (lane == 0) { red[4 + wave] = q; red[8 + wave] = dm; }
-    __syncthreads();
-    if (tid == 0) {
-      float* o = tile_stats + ((size_t)b * tiles_x * tiles_y + ty * tiles_x + tx) * SGG_TS;
+    q = wave_sum_dpp(q);
+    dm = wave_max_dpp(dm);
+    if (lane == 0) {
+      float* o = tile_stats + ((((size_t)b * tiles_y + ty) * tiles_x + tx) * 4 + wave) * SGG_TS;
       o[0] = cnt;
-      o[1] = mean_t;
-      o[2] = red[4] + red[5] + red[6] + red[7];
-      o[3] = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+      o[1] = mean_w;
+      o[2] = q;
+      o[3] = dm;
     }
   }
   }
@@ -825,7 +845,7 @@ extern "C" int sgg_hwio_to_hwoi(const float* w, float* wt, int taps, int cin, in
 // (0 = not available for this shape / precision: use the LayerNorm's own statistics pass).
 extern "C" int sgg_conv2d_nhwc_fwd_tile_stats(int Ho, int Wo, int Cin, int Cout, int KH, int KW, int stride, int precision,
                                               int w_split_layout) {
-  if (Cin == 3) return (KH == 3 && KW == 3 && stride == 1 && Cout == 32) ? sgg_cdiv(Ho, 8) * sgg_cdiv(Wo, 32) : 0;   // any precision
+  if (Cin == 3) return (KH == 3 && KW == 3 && stride == 1 && Cout == 32) ? 4 * sgg_cdiv(Ho, 8) * sgg_cdiv(Wo, 32) : 0;   // any precision: one per wave
   if (precision == 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
   if (w_split_layout == 1 || w_split_layout == 4) {
     if (!sgg_halo_applicable(KH, KW, stride, Ho, Wo, Cin, Cout, precision)) return 0;

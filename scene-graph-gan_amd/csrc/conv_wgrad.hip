@@ -484,6 +484,12 @@ static void launch_slab_reduce(const float* slabs, float* out, long long n4, int
 // (108 FMAs per pixel and 4 channels) took 3456.  One LDS reduction of the four waves per workgroup at the end, then the
 // deterministic slab reduce.  Sums: pixels in tile order per wave (exact f32 fmaf chains, mma_f32.h).
 // ---------------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS accesses only (__syncthreads() would also drain the prefetched global loads)
+__device__ __forceinline__ void c3w_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 __global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ slabs, int H, int W, int pt, int pl,
                                                                int tiles_x, int tiles_y, int ntiles, int tiles_per_wg) {
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __re
   };
   load_tile(t_begin);
   for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();
+    c3w_lds_barrier();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int idx = tid + 256 * k;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __re
         dv[m][4 * q] = dvn[m][4 * q]; dv[m][4 * q + 1] = dvn[m][4 * q + 1]; dv[m][4 * q + 2] = dvn[m][4 * q + 2]; dv[m][4 * q + 3] = dvn[m][4 * q + 3];
         sgg_quad_transpose4(dv[m][4 * q], dv[m][4 * q + 1], dv[m][4 * q + 2], dv[m][4 * q + 3], lane);
       }
-    __syncthreads();
+    c3w_lds_barrier();
     load_tile(t + 1);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __re
   // the four waves' tiles -> one [27][32] slab of the workgroup (register r of lane (i, h): tap acc_row(r, lane), channel i)
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[(wave * 32 + acc_row(r, lane)) * 32 + i] = acc[r];
-  __syncthreads();
+  c3w_lds_barrier();
   for (int e = tid; e < 27 * COUT; e += 256)
     slabs[(size_t)blockIdx.x * 27 * COUT + e] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
 }

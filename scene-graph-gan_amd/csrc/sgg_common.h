@@ -51,6 +51,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// The same reductions without the LDS crossbar: four DPP steps inside a row of 16 lanes (quad permutes, half-row and row mirror),
+// then the four row sums through v_readlane.  wave_sum / wave_max above cost six ds_bpermute round trips each (~100 cycles apiece,
+// dependent): nothing behind a long K loop, but a third of a tile's time in the conv1_1 forward (28 MFMAs per tile).  Another
+// summation order than wave_sum (results differ in the last bits); every lane returns the same value.
+#define SGG_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += SGG_DPP(v, 0xB1);       // quad_perm [1,0,3,2]: lane ^ 1
+  v += SGG_DPP(v, 0x4E);       // quad_perm [2,3,0,1]: lane ^ 2
+  v += SGG_DPP(v, 0x141);      // row_half_mirror: the other quad of the 8
+  v += SGG_DPP(v, 0x140);      // row_mirror: the other half of the 16
+  const int b = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, SGG_DPP(v, 0xB1));
+  v = fmaxf(v, SGG_DPP(v, 0x4E));
+  v = fmaxf(v, SGG_DPP(v, 0x141));
+  v = fmaxf(v, SGG_DPP(v, 0x140));
+  const int b = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48))));
+}
+
 // block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS. All threads get the sum.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = wave_sum(v);

@@ -35,8 +35,12 @@ if mode.endswith("_ln"):        # LN prologue timing: identity statistics (mean 
     stats = torch.zeros((B, 2), device="cuda"); stats[:, 1] = 1.0
     ln = (stats, torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda"))
     K.split_weights(wf, ws, am[1:2], lay)
+ts = None
+if mode == "fwd_stats":          # forward with the LayerNorm partials in the epilogue (conv1_1 as the trunk calls it)
+    ts = torch.empty((B, K.conv_tile_stats_count((B, Ho, Ho, Co), Ci, k, s, lay), 4), device="cuda")
 def run():
     if mode == "fwd": K.conv_fwd(x, w, wf, b, y, s)
+    elif mode == "fwd_stats": K.conv_fwd(x, w, wf if Ci != 3 else w, b, y, s, tile_stats=ts)
     elif mode == "fwd_ws": K.conv_fwd(x, w, wf, b, y, s, ws, am[0:1], am[1:2], None, lay)
     elif mode == "fwd_ws_ln": K.conv_fwd(x, w, wf, b, y, s, ws, am[0:1], am[1:2], None, lay, ln=ln)
     elif mode == "wgrad_ln": K.conv_wgrad(x, dy, dw, s, am[0:1], amdy, ln=ln)

@@ -512,7 +512,7 @@ def test_conv_c3_tile_stats(hip, ref, shape):
     x, w, b = rnd((B, H, W, 3), 70), rnd((3, 3, 3, 32), 71, 0.2), rnd((32,), 72, 0.5)
     xd, wd, bd = dev(x), dev(w), dev(b)
     nts = hip.conv_tile_stats_count((B, H, W, 32), 3, 3, 1, 0)
-    assert nts == -(-H // 8) * -(-W // 32)
+    assert nts == 4 * (-(-H // 8) * -(-W // 32))          # one record per wave: two rows x 32 columns of an 8 x 32 tile
     ts = torch.full((B, nts, 4), float("nan"), device="cuda")
     y = torch.full((B, H, W, 32), float("nan"), device="cuda")
     hip.conv_fwd(xd, wd, wd, bd, y, 1, tile_stats=ts)
