@@ -162,6 +162,9 @@ DEFAULT_OPTIONS = {
     "wgrad_late": True,
     # two-stream schedule: HIP priority of the side streams (0 = default; positive = lower than the main stream's, negative = higher)
     "side_priority": 0,
+    # two-stream schedule: 1 = G's encoder forward of the update after a critic update starts on a stream of its own as soon as that
+    # critic update's G head has run, beside its heads and encoder backward (step.GanStep._g_early_stream)
+    "g_early": 1,
     # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward /
     # never fuse in passes with backward
     "ln_fusion_skip": (),

@@ -132,7 +132,22 @@ class GanStep:
         self.D.head.enable_side_stream(self.head_side)
 
     # ------------------------------------------------------------------------------------------------
-    def generator_forward(self, images, noise, for_backward=True):
+    def _g_early_stream(self, images):
+        """Option g_early (default on, two-stream schedule): G's encoder forward of THIS update depends on nothing the previous update
+        still computes once that update's G head has run (a critic update leaves G's weights alone): it may start on a stream of its
+        own right there - beside the critic's heads, which are a chain of short launches that leaves the chip idle, and its encoder
+        backward.  Returns that stream (already waiting for the event), or None.  Same kernels, same operands: bit-identical;
+        43.17 / 43.15 against 43.60 / 43.73 ms per step (profiles/r04_g_early_ab.log)."""
+        ev = getattr(self, "_ev_g_free", None)
+        self._ev_g_free = None
+        if self.side is None or ev is None or not getattr(self.K, "g_early", 0) or self.G.pending is not None or self._g_reuse is not None:
+            return None
+        if getattr(self, "xs", None) is None:
+            self.xs = torch.cuda.Stream(device=images.device)
+        self.xs.wait_event(ev)
+        return self.xs
+
+    def generator_forward(self, images, noise, for_backward=True, early=None):
         """Generator.build_generator: fake logits [B,3,V] (a view of the critic's input slab).
 
         Inside train_iteration(..., reuse_g_encoder=True) G's ENCODER runs once per iteration: every update of an iteration sees
@@ -150,8 +165,14 @@ class GanStep:
             ctx = self._g_reuse[1]
         else:
             keep = for_backward or self._g_reuse_armed
-            ctx = G.trunk.forward(images, keep) if keep is False else G.trunk.forward(images)
-            G.head.precompute(ctx)
+            if early is not None:        # (the caller made `early` wait for everything this forward depends on)
+                with torch.cuda.stream(early):
+                    ctx = G.trunk.forward(images, keep) if keep is False else G.trunk.forward(images)
+                    G.head.precompute(ctx)
+                torch.cuda.current_stream().wait_stream(early)
+            else:
+                ctx = G.trunk.forward(images, keep) if keep is False else G.trunk.forward(images)
+                G.head.precompute(ctx)
             if self._g_reuse_armed:
                 self._g_reuse = (images, ctx, (images.data_ptr(), images._version, G.adam_t))
         st = G.head.state(1, self.B)
@@ -193,13 +214,18 @@ class GanStep:
         # last generator step hides under D's encoder; critic_iters > 1: D's reduce from the previous critic update
         # hides under G's forward).  With a side stream the wait is enqueued there and never blocks the main stream.
         if D.pending is None or self.side is not None:
+            early = self._g_early_stream(images)      # (critic_iters > 1: after another critic update)
             ctx = self._d_encoder_on_side_stream(images, zero_grads=True)
             self.G.finish_update()
-            gst, _ = self.generator_forward(images, noise, for_backward=False)     # the critic update never differentiates G
+            gst, _ = self.generator_forward(images, noise, for_backward=False, early=early)     # the critic update never differentiates G
         else:
             self.G.finish_update()
             gst, _ = self.generator_forward(images, noise, for_backward=False)
             ctx = self._d_encoder_on_side_stream(images, zero_grads=True)
+        if self.side is not None and getattr(K, "g_early", 0):
+            # G's encoder buffers are free from here on, and this critic update does not touch G's weights (_g_early_stream)
+            self._ev_g_free = torch.cuda.Event()
+            self._ev_g_free.record()
         self._join_side()
         fake_rows.copy_(gst.OUT[0])
         K.onehot(labels, real_rows)
@@ -269,8 +295,9 @@ class GanStep:
         G.finish_update()
         G.zero_grads()
         if D.pending is None or self.side is not None:
+            early = self._g_early_stream(images)
             ctx = self._d_encoder_on_side_stream(images, zero_grads=False, for_backward=False)   # independent of G's forward
-            gst, gctx = self.generator_forward(images, noise)
+            gst, gctx = self.generator_forward(images, noise, early=early)
         else:
             # the critic-gradient all-reduce launched at the end of critic_step runs under G's forward; only then does
             # D.finish_update() wait for it
