@@ -138,9 +138,14 @@ class GanStep:
         own right there - beside the critic's heads, which are a chain of short launches that leaves the chip idle, and its encoder
         backward.  Returns that stream (already waiting for the event), or None.  Same kernels, same operands: bit-identical;
         43.17 / 43.15 against 43.60 / 43.73 ms per step (profiles/r04_g_early_ab.log)."""
-        ev = getattr(self, "_ev_g_free", None)
-        self._ev_g_free = None
+        ev, ev_images = getattr(self, "_ev_g_free", None), getattr(self, "_ev_g_images", None)
+        self._ev_g_free = self._ev_g_images = None
         if self.side is None or ev is None or not getattr(self.K, "g_early", 0) or self.G.pending is not None or self._g_reuse is not None:
+            return None
+        # only for the minibatch tensor the critic update ran on, unmodified (train.py:175-190 repeats each batch for every update of an
+        # iteration): the early stream waits for nothing the main stream enqueued after that update's G head, so a tensor produced there
+        # since (another batch, an augmentation in place) would be read too early
+        if ev_images is None or ev_images[0] is not images or ev_images[1] != images._version:
             return None
         if getattr(self, "xs", None) is None:
             self.xs = torch.cuda.Stream(device=images.device)
@@ -226,6 +231,7 @@ class GanStep:
             # G's encoder buffers are free from here on, and this critic update does not touch G's weights (_g_early_stream)
             self._ev_g_free = torch.cuda.Event()
             self._ev_g_free.record()
+            self._ev_g_images = (images, images._version)
         self._join_side()
         fake_rows.copy_(gst.OUT[0])
         K.onehot(labels, real_rows)
