@@ -103,6 +103,24 @@ def run_modes(hip, x, w, b, dy, s, what, do=("fwd", "dgrad", "wgrad")):
                 dw = torch.full(tuple(w.shape), float("nan"), device="cuda")
                 hip.conv_wgrad(xd, dyd, dw, s)
                 out["wgrad"][mode] = rel_err(dw, refs["wgrad"])
+                if mode == 2 and x.shape[3] % 32 == 0 and hasattr(hip, "presplit16") and \
+                        hip.wgrad_resident(x.shape[0], dy.shape[1], dy.shape[2], x.shape[3], dy.shape[3], k, s):
+                    # the round-4 product path: BOTH operands pre-split (as the LayerNorm kernels write them; here through
+                    # sgg_presplit16 under the tensors' maxima) -> the LDS-DMA filter-gradient kernel where the shape takes it (8x8
+                    # blocks or row bands, 64+ channels), the register-staged kernel without arithmetic otherwise; same bound
+                    am = torch.zeros(2, device="cuda")
+                    hip.absmax(xd, am[0:1])
+                    hip.absmax(dyd, am[1:2])
+                    x16, dy16 = torch.empty_like(xd), torch.empty_like(dyd)
+                    hip.presplit16(xd, x16, am[0:1])
+                    hip.presplit16(dyd, dy16, am[1:2])
+                    dw2 = torch.full(tuple(w.shape), float("nan"), device="cuda")
+                    hip.conv_wgrad(x16, dy16, dw2, s, am[0:1], am[1:2], x_s16=True, dy_s16=True)
+                    e = rel_err(dw2, refs["wgrad"])
+                    print("%-34s wgrad err f16x3 product path (pre-split operands) %.3e" % (what, e))
+                    ERRORS["%s/wgrad_presplit" % what] = {"f16x3": e}
+                    out["wgrad"][2] = max(out["wgrad"][2], e)
+                    del x16, dy16, dw2
     finally:
         hip.conv_precision = old
     for op, e in out.items():
