@@ -4,6 +4,8 @@ image size it first sees and for every batch size it is called with, shares ONE 
 (generator_with_attention.py:16,68,74,75)."""
 from __future__ import annotations
 
+import collections
+
 import torch
 
 from .lib import HipKernels
@@ -27,7 +29,13 @@ class NetworkHandle(object):
     def __init__(self, kind, vocab_size):
         self.kind, self.vocab_size = kind, int(vocab_size)
         self.net = None              # the network of the first batch size seen (owner of the parameter arenas)
-        self._nets = {}              # batch size -> Network sharing those arenas
+        # batch size -> Network sharing those arenas, least recently used first.  Every entry owns the encoder / head activation buffers
+        # of its batch size (multi-GB at 224x224), so the cache is BOUNDED: the owner plus the max_cached_batch_sizes - 1 most recently
+        # used others (train.py needs three: B, VAL_BATCH_SIZE = B / 2 and the test pass); a caller that feeds ever-changing batch sizes
+        # (a last partial batch, ad-hoc sampling) re-creates buffers instead of growing until the allocator fails.  An evicted Network
+        # that a caller still holds (a GanStep built on it) stays valid - it only leaves this cache.
+        self._nets = collections.OrderedDict()
+        self.max_cached_batch_sizes = 4
         self._last = None            # the network of the most recent build (attention / attributes refer to it)
         self.embedding_matrix = None
         self.init_seed = 3
@@ -54,7 +62,12 @@ class NetworkHandle(object):
                              % (self.net.trunk.S, self.net.trunk.S, S, S))
         net = self._nets.get(B)
         if net is None:
+            for b in [b for b, n in self._nets.items() if n is not self.net and n is not self._last]:
+                if len(self._nets) < self.max_cached_batch_sizes:
+                    break
+                del self._nets[b]         # least recently used first
             net = self._nets[B] = Network(self.net.K, self.kind, self.vocab_size, S, B, self.net.arena.E, share=self.net)
+        self._nets.move_to_end(B)
         net.finish_update()          # (a deferred optimiser step of a data-parallel run is applied before the weights are read)
         self._last = net
         return net

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_s2_kernel(S2Par
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :
                      : "s"(la + (unsigned)(j * (NT * 16) + pp * S2_PLB)), "v"(off), "s"(rs), "s"(pp * 64)
-                     : "memory");
+                     : "memory", "m0");      // (M0 is written here: declared, so no compiler-held value can live across it)
     }
     if (++s_stage == nstage) {
       s_stage = 0;

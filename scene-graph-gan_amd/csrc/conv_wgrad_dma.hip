@@ -38,7 +38,7 @@ __device__ __forceinline__ void wd_dma16(wd_v4i rs, unsigned lds_addr, unsigned 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
                : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
-               : "memory");      // (M0 has no other user in this kernel: every LDS read is a plain ds_read)
+               : "memory", "m0");      // (M0 is written here: declared, so no compiler-held value can live across it)
 }
 __device__ __forceinline__ wd_v4i wd_rsrc(const void* base, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(base);

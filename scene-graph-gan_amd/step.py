@@ -147,6 +147,11 @@ class GanStep:
         # since (another batch, an augmentation in place) would be read too early
         if ev_images is None or ev_images[0] is not images or ev_images[1] != images._version:
             return None
+        # ... and only for the parameters that critic update left: a state-dict load or an optimiser step through another batch size's
+        # Network on the shared arena since then would make trunk.forward re-derive the weight formats (refresh_weights) on the early
+        # stream, unordered against the main stream's writes
+        if ev_images[2] != (self.G.arena.version, self.G.adam_t):
+            return None
         if getattr(self, "xs", None) is None:
             self.xs = torch.cuda.Stream(device=images.device)
         self.xs.wait_event(ev)
@@ -231,7 +236,7 @@ class GanStep:
             # G's encoder buffers are free from here on, and this critic update does not touch G's weights (_g_early_stream)
             self._ev_g_free = torch.cuda.Event()
             self._ev_g_free.record()
-            self._ev_g_images = (images, images._version)
+            self._ev_g_images = (images, images._version, (self.G.arena.version, self.G.adam_t))
         self._join_side()
         fake_rows.copy_(gst.OUT[0])
         K.onehot(labels, real_rows)

@@ -95,6 +95,11 @@ def test_model_objects_are_batch_dynamic_on_one_set_of_weights():
     assert float((gp2["conv2d/kernel"] - gp["conv2d/kernel"]).abs().max()) > 0 and float((dp2["W"] - dp["W"]).abs().max()) > 0
     check(4, gp2, dp2, "after the update at B = 8")          # the B = 4 encoder re-derives its operand formats from the new weights
     check(8, gp2, dp2, "after the update at B = 8")
+    # the per-batch-size buffer cache is bounded (owner + the most recently used others): ever-changing batch sizes do not grow it
+    for b in (2, 3, 5, 6, 7):
+        g.build_generator(torch.zeros((b, S, S, 3), device="cuda"))
+    assert len(g._nets) <= g.max_cached_batch_sizes and g._nets[8] is g.net and 7 in g._nets and 4 not in g._nets
+    check(4, gp2, dp2, "B = 4 re-created after its eviction")
     with pytest.raises(ValueError):
         g.build_generator(torch.zeros((2, 96, 96, 3), device="cuda"))       # the spatial size is static, as in the reference (:15)
 

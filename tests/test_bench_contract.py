@@ -64,7 +64,7 @@ def test_cli_contract_flags_exist():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--critic-iters", "--cpu-rows", "--f32-steps", "--serial-steps", "--single-stream",
-                 "--other-configs"):
+                 "--other-configs", "--other-oracle-rows", "--bitwise-iters"):
         assert flag in out.stdout
 
 
@@ -113,6 +113,11 @@ def test_bench_line_names_its_schedule_and_measures_the_roofline_in_serial_steps
     assert r["bound"] == "mfma" and r["launches_per_step"] * r["avg_launch_ms"] <= rec["serial"]["ms_per_step"]
     assert any(h["kernel"].startswith("conv_c3") for h in rec["roofline_hbm"]), [h["kernel"] for h in rec["roofline_hbm"]]
     assert rec["parity"]["ok"] is True and rec["cpu_baseline"]["kind"] == "port" and rec["native_f32"]["steps"] == 1
+    # the oracle record is about the schedule that was timed, and that schedule is bit-identical to the serial one at the timed size
+    sch = rec["parity"]["precision2_vs_oracle"]["schedule"]
+    assert sch["overlap_streams"] and sch["head_side_stream"] and sch["g_early_fired"], sch
+    assert rec["parity"]["two_stream_bitwise_at_full_size"] is True and rec["parity"]["two_stream_bitwise_detail"]["g_early_fired"]
+    assert rec["parity"]["precision2_vs_oracle"]["margin_over_logit_tolerance"] > 4.0
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "4", "--size", "64",
                           "--vocab", "50", "--cpu-rows", "0", "--f32-steps", "0", "--ci10-steps", "0", "--serial-steps", "0", "--single-stream"],
                          capture_output=True, text=True, timeout=900)

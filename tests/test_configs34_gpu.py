@@ -18,6 +18,7 @@ import torch
 import sgg_amd  # noqa: F401
 from oracle import sgg_oracle as O
 from sgg_amd.step import GanStep
+from tolerances import GRAD_RTOL, logit_tol, loss_tol
 
 pytestmark = pytest.mark.gpu
 GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -178,7 +179,7 @@ def test_step_matches_oracle_and_golden(hip, gold, B, S, V):
     st, _ = gs.generator_forward(images.cuda(), noise0.cuda())
     logits = st.OUT[0].cpu()
     ref_logits = O.generator_forward(gp, images, noise0)
-    tol = 1e-4 + 1e-4 * float(ref_logits.abs().max())
+    tol = logit_tol(ref_logits.abs().max())
     assert float((logits - ref_logits).abs().max()) <= tol
     gl = G["g_logits_step0"]
     sub = logits.numpy() if gl.shape == tuple(logits.shape) else logits.numpy()[..., ::97]
@@ -189,22 +190,22 @@ def test_step_matches_oracle_and_golden(hip, gold, B, S, V):
     d_adam, g_adam = O.new_adam_state(dp), O.new_adam_state(gp)
     cost, aux, dgrads = O.d_step(gp, dp, d_adam, 1, images, onehot, noise0, alpha)
     dl = gs.critic_step(images.cuda(), labels.cuda(), noise0.cuda(), alpha.reshape(B).cuda()).cpu()
-    assert abs(float(dl[0]) - float(cost)) <= 1e-4 + 1e-4 * abs(float(cost)), (dl, cost)
-    assert abs(float(dl[0]) - float(G["disc_cost"])) <= 1e-4 + 1e-4 * abs(float(G["disc_cost"]))
-    assert abs(float(dl[2]) - float(aux["gp"])) <= 1e-4 + 1e-3 * abs(float(aux["gp"]))
+    assert abs(float(dl[0]) - float(cost)) <= loss_tol(cost), (dl, cost)
+    assert abs(float(dl[0]) - float(G["disc_cost"])) <= 10 * loss_tol(G["disc_cost"])     # (golden: the oracle on another host)
+    assert abs(float(dl[2]) - float(aux["gp"])) <= 1e-5 + 1e-4 * abs(float(aux["gp"]))
     worst = max((tensor_err(gs.D.grads[n], gr), n) for n, gr in dgrads.items() if n != "decoder/bias")
     print("critic gradients: worst rel err %.3e (%s)" % worst)
-    assert worst[0] < 1e-3, "critic gradient %s: rel err %.3e" % (worst[1], worst[0])
+    assert worst[0] < GRAD_RTOL, "critic gradient %s: rel err %.3e" % (worst[1], worst[0])
 
     gs.D.arena.load_state_dict(dp)            # generator step on identical critic weights (tests/test_step_gpu.py)
     gs.D.trunk.refresh_weights()
     gcost, gaux, ggrads = O.g_step(gp, dp, g_adam, 1, images, noise1)
     glv = gs.generator_step(images.cuda(), noise1.cuda()).cpu()
-    assert abs(-float(glv[3]) - float(gcost)) <= 1e-4 + 1e-4 * abs(float(gcost))
-    assert abs(-float(glv[3]) - float(G["gen_cost"])) <= 2e-4 + 2e-4 * abs(float(G["gen_cost"]))
+    assert abs(-float(glv[3]) - float(gcost)) <= loss_tol(gcost)
+    assert abs(-float(glv[3]) - float(G["gen_cost"])) <= 10 * loss_tol(G["gen_cost"])
     worst = max((tensor_err(gs.G.grads[n], gr), n) for n, gr in ggrads.items())
     print("generator gradients: worst rel err %.3e (%s)" % worst)
-    assert worst[0] < 1e-3, "generator gradient %s: rel err %.3e" % (worst[1], worst[0])
+    assert worst[0] < GRAD_RTOL, "generator gradient %s: rel err %.3e" % (worst[1], worst[0])
     toks = gs.argmax_tokens(gs.G.head.state(1, B).OUT[0]).cpu()
     margin = O.top2_margin(gaux["fake"])
     print("min top-2 logit margin: %.3e" % margin)

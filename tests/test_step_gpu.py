@@ -2,9 +2,10 @@
 oracle on identical seeded inputs (BASELINE.json configs[0]: 8 x 64x64 images, vocab 50).
 
 Tolerances (fp32 on both sides, different summation orders):
-  losses / logits / critic outputs: |d| <= 1e-4 + 1e-4*|ref|
-  gradients and post-Adam weights : max|d| <= 1e-3 * max|ref| per tensor (+ floor 1e-7)
-  arg-maxed triple tokens         : exact, with the minimum top-2 logit margin reported
+  losses                          : |d| <= 2e-6 + 2e-6*|ref|      (tests/tolerances.py: ~10x what is measured)
+  logits                          : |d| <= 1e-5 + 1e-5*max|ref|
+  gradients                       : max|d| <= 2e-4 * max|ref| per tensor (+ floor 1e-7)
+  arg-maxed triple tokens         : exact; the seeds' minimum top-2 logit margin exceeds 4x the logit tolerance
 """
 import pytest
 import torch
@@ -12,6 +13,7 @@ import torch
 import sgg_amd  # noqa: F401
 from oracle import sgg_oracle as O
 from sgg_amd.step import GanStep
+from tolerances import GRAD_RTOL, MARGIN_FACTOR, logit_tol, loss_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -49,19 +51,19 @@ def test_gd_step_matches_oracle_config1(hip, scale_emb):
     # forward parity of the generator alone
     st, _ = gs.generator_forward(images.cuda(), noise0.cuda())
     ref_logits = O.generator_forward(gp, images, noise0)
-    assert float((st.OUT[0].cpu() - ref_logits).abs().max()) <= 1e-4 + 1e-4 * float(ref_logits.abs().max())
+    assert float((st.OUT[0].cpu() - ref_logits).abs().max()) <= logit_tol(ref_logits.abs().max())
 
     d_adam, g_adam = O.new_adam_state(dp), O.new_adam_state(gp)
     cost, aux, dgrads = O.d_step(gp, dp, d_adam, 1, images, onehot, noise0, alpha)
     if scale_emb > 1:
         assert float(aux["gp"]) > 1e-3
     dl = gs.critic_step(images.cuda(), labels.cuda(), noise0.cuda(), alpha.reshape(B).cuda()).cpu()
-    assert abs(float(dl[0]) - float(cost)) <= 1e-4 + 1e-4 * abs(float(cost)), (dl, cost)
-    assert abs(float(dl[2]) - float(aux["gp"])) <= 1e-4 + 1e-3 * abs(float(aux["gp"])), (dl, aux["gp"])
+    assert abs(float(dl[0]) - float(cost)) <= loss_tol(cost), (dl, cost)
+    assert abs(float(dl[2]) - float(aux["gp"])) <= 1e-5 + 1e-4 * abs(float(aux["gp"])), (dl, aux["gp"])
     # the critic's decoder bias gradient cancels analytically (+1 from the fake rows, -1 from the real rows, 0 from GP)
     assert float(gs.D.grads["decoder/bias"].abs().max()) < 1e-5 and float(dgrads["decoder/bias"].abs().max()) < 1e-5
     worst = max((tensor_err(gs.D.grads[n], g), n) for n, g in dgrads.items() if n != "decoder/bias")
-    assert worst[0] < 1e-3, "critic gradient %s: rel err %.3e" % (worst[1], worst[0])
+    assert worst[0] < GRAD_RTOL, "critic gradient %s: rel err %.3e" % (worst[1], worst[0])
     check_weights_after_adam(gs.D.arena.views, dp, {n: g for n, g in dgrads.items() if n != "decoder/bias"}, dp0, 1, "critic")
 
     # compare the generator step on IDENTICAL critic weights: the first Adam step moves noise-level gradient
@@ -71,15 +73,15 @@ def test_gd_step_matches_oracle_config1(hip, scale_emb):
     gs.D.trunk.refresh_weights()
     gcost, gaux, ggrads = O.g_step(gp, dp, g_adam, 1, images, noise1)
     gl = gs.generator_step(images.cuda(), noise1.cuda()).cpu()
-    assert abs(-float(gl[3]) - float(gcost)) <= 1e-4 + 1e-4 * abs(float(gcost))
+    assert abs(-float(gl[3]) - float(gcost)) <= loss_tol(gcost)
     worst = max((tensor_err(gs.G.grads[n], g), n) for n, g in ggrads.items())
-    assert worst[0] < 1e-3, "generator gradient %s: rel err %.3e" % (worst[1], worst[0])
+    assert worst[0] < GRAD_RTOL, "generator gradient %s: rel err %.3e" % (worst[1], worst[0])
     check_weights_after_adam(gs.G.arena.views, gp, ggrads, gp0, 1, "generator")
 
     toks = gs.argmax_tokens(gs.G.head.state(1, B).OUT[0]).cpu()
     margin = O.top2_margin(gaux["fake"])
     print("min top-2 logit margin: %.3e" % margin)
-    assert margin > 1e-4, "seed gives an argmax margin inside the fp tolerance"
+    assert margin > MARGIN_FACTOR * logit_tol(gaux["fake"].abs().max()), "seed gives an argmax margin inside the fp tolerance"
     assert torch.equal(toks, O.argmax_tokens(gaux["fake"]))
 
 
