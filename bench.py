@@ -277,14 +277,19 @@ def two_stream_bitwise_leg(K, B, S, V, iterations=2, critic_iters=2):
 
     def run(two):
         gs = GanStep(K, V, S, B, lam=10.0, g_state=g0, d_state=d0, overlap_streams=two)
-        for it in range(iterations):
+        gp_first = None
+        for it in range(iterations):            # (GanStep.train_iteration's loop body, train.py:362-368)
             o = it * (critic_iters + 1)
-            gs.train_iteration(images, labels, noises[o:o + critic_iters + 1], alphas[o:o + critic_iters], critic_iters=critic_iters)
+            for i in range(critic_iters):
+                gs.critic_step(images, labels, noises[o + i], alphas[o + i])
+                if gp_first is None:
+                    gp_first = gs.d_losses[2:3].clone()      # (the penalty, i.e. the second-order path, is active in the first update)
+            gs.generator_step(images, noises[o + critic_iters])
         gs.flush()
         torch.cuda.synchronize(dev)
         snap = {"G.weights": gs.G.arena.flat.clone(), "D.weights": gs.D.arena.flat.clone(), "G.adam_m": gs.G.m_flat.clone(),
                 "D.adam_m": gs.D.m_flat.clone(), "G.adam_v": gs.G.v_flat.clone(), "D.adam_v": gs.D.v_flat.clone(),
-                "losses": torch.cat([gs.d_losses, gs.g_losses]).clone()}
+                "losses": torch.cat([gs.d_losses, gs.g_losses, gp_first]).clone()}
         fired = getattr(gs, "xs", None) is not None
         del gs
         torch.cuda.empty_cache()
@@ -294,7 +299,7 @@ def two_stream_bitwise_leg(K, B, S, V, iterations=2, critic_iters=2):
     bad = [k for k in ref if not torch.equal(ref[k], got[k])]
     finite = all(bool(torch.isfinite(v).all()) for v in got.values())
     return {"equal": not bad and finite, "differing": bad, "finite": finite, "iterations": iterations, "critic_iters": critic_iters,
-            "g_early_fired": fired, "gp_last": float(got["losses"][2]),
+            "g_early_fired": fired, "gp_first_update": float(got["losses"][8]), "gp_last_update": float(got["losses"][2]),
             "compared": "flat parameter arenas, Adam m and v arenas of G and D, last losses: torch.equal, serial vs multi-stream schedule, "
                         "batch %d, %dx%d, vocab %d" % (B, S, S, V)}
 

@@ -18,7 +18,7 @@ import torch
 import sgg_amd  # noqa: F401
 from oracle import sgg_oracle as O
 from sgg_amd.step import GanStep
-from tolerances import GRAD_RTOL, logit_tol, loss_tol
+from tests.tolerances import GRAD_RTOL, logit_tol, loss_tol
 
 pytestmark = pytest.mark.gpu
 GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

@@ -44,7 +44,7 @@ def test_bench_rendezvous_over_rccl():
 def test_two_rank_rccl_step_equals_single_process(hip, tmp_path):
     from oracle import sgg_oracle as O
     from sgg_amd.step import GanStep, tf_adam_lr_t
-    from tolerances import GRAD_RTOL, loss_tol
+    from tests.tolerances import GRAD_RTOL, loss_tol
     prefix = str(tmp_path / "rank")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "2",
            os.path.join(ROOT, "tests", "dp_rccl_worker.py"), prefix]

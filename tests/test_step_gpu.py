@@ -13,7 +13,7 @@ import torch
 import sgg_amd  # noqa: F401
 from oracle import sgg_oracle as O
 from sgg_amd.step import GanStep
-from tolerances import GRAD_RTOL, MARGIN_FACTOR, logit_tol, loss_tol
+from tests.tolerances import GRAD_RTOL, MARGIN_FACTOR, logit_tol, loss_tol
 
 pytestmark = pytest.mark.gpu
 
