@@ -574,6 +574,21 @@ __device__ __forceinline__ void c3_lds_barrier() {
 // patch offset of tap k = (kh * 3 + kw) * 3 + ci in the planar 10 x 36 image (k = 27: the zero column of the contraction)
 __host__ __device__ constexpr int c3_tap_off(int k) { return k < 27 ? (k % 3) * 360 + (k / 9) * 36 + (k / 3) % 3 : 0; }
 
+// conv1_1's output stores: the kernel is a 91 % WRITE stream (411 MB per launch at batch 64) of whole 128-byte lines.  Measured with
+// scripts/ubench/counter_calib.hip (profiles/r05_counter_calibration.log): a pure stream of 16-byte NONTEMPORAL stores sustains
+// 4.9 - 5.0 TB/s on this chip, default-policy stores 6.7 TB/s and more - the nontemporal hint that pays in the MFMA-bound epilogues
+// (SGG_CONV_NT_STORE) caps this kernel at its own store rate.  -DSGG_C3_NT_STORE=1 restores the hint.
+#ifndef SGG_C3_NT_STORE
+#define SGG_C3_NT_STORE 0
+#endif
+__device__ __forceinline__ void c3_out_store4(float* p, const f32x4& v) {     // p 16-byte aligned
+#if SGG_C3_NT_STORE
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 __global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ tile_stats, int H, int W, int pt, int pl,
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(256, 4) void conv_c3_fwd_kernel(const float* __rest
 #ifdef C3_ABL_NOSTORE
       if (v0 == 12345.678f)
 #endif
-      if (full || (yy < H && 8 * q + (i & 3) < cmax)) sgg_out_store4(ybase + 8 * q * COUT, f32x4{v0, v1, v2, v3});
+      if (full || (yy < H && 8 * q + (i & 3) < cmax)) c3_out_store4(ybase + 8 * q * COUT, f32x4{v0, v1, v2, v3});
     }
   }
   if (tile_stats) {

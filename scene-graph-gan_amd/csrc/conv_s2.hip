@@ -250,7 +250,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_s2_kernel(S2Par
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :
                      : "s"(la + (unsigned)(j * (NT * 16) + pp * S2_PLB)), "v"(off), "s"(rs), "s"(pp * 64)
-                     : "memory", "m0");      // (M0 is written here: declared, so no compiler-held value can live across it)
+                     : "memory");      // (M0: a RESERVED register of this target - the compiler keeps no value in it across statements and
+                                       //  rejects it in a clobber list (-Winline-asm); build.check_m0_users verifies on the linked code
+                                       //  objects that this kernel has no other M0 user)
     }
     if (++s_stage == nstage) {
       s_stage = 0;
@@ -595,7 +597,7 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
     (void)hipMemsetAsync(p.out, 0, (size_t)(dgrad ? 4 : 1) * p.M * p.N * sizeof(float), st);
   const int ntn = (p.N / bn) * p.ksplit;
   p.nbands = sgg_cdiv(p.M, 32 * mt);
-  const int slots = wide ? 32 : 64;                // resident workgroups per XCD (32 CUs)
+  const int slots = wide ? SGG_PERSIST_CUS_PER_XCD : 2 * SGG_PERSIST_CUS_PER_XCD;      // resident workgroups per XCD (32 CUs)
   int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile, channel half) items an XCD owns
   int gx = per_xcd < slots ? per_xcd : slots;
   gx = sgg_cdiv(gx, ntn) * ntn;

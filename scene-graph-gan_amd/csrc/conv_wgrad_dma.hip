@@ -38,7 +38,10 @@ __device__ __forceinline__ void wd_dma16(wd_v4i rs, unsigned lds_addr, unsigned 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
                : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
-               : "memory", "m0");      // (M0 is written here: declared, so no compiler-held value can live across it)
+               : "memory");      // (M0 is a RESERVED register of this target: the compiler keeps no value in it across statements and warns
+                                 //  about it in a clobber list (-Winline-asm); that this kernel has no other M0 user - movrel indexing,
+                                 //  a readlane lane select, the LDS-DMA builtin - is verified on the linked code objects by
+                                 //  build.check_m0_users)
 }
 __device__ __forceinline__ wd_v4i wd_rsrc(const void* base, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(base);

@@ -142,6 +142,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 #endif
 
+// CUs per XCD that the PERSISTENT forward / dgrad convolution kernels occupy (one 8-wave workgroup, or two 4-wave ones, per CU; an XCD
+// has 32).  Fewer than 32 leaves whole CUs - registers, wave slots - to the HBM-bound kernels of the other HIP streams (LayerNorm
+// passes of the other network, Adam, the heads), which cannot co-reside with a workgroup that holds a CU's whole register file.
+// Experiment of round 5 (profiles/r05_persistent_cu_cap_ab.log); 32 = every CU.
+#ifndef SGG_PERSIST_CUS_PER_XCD
+#define SGG_PERSIST_CUS_PER_XCD 32
+#endif
+
 // The resident convolution kernels raise the wave's issue priority over their MFMA clusters (s_setprio), so that the other resident
 // workgroup's wave in its staging phase does not take issue slots from the wave feeding the matrix pipe (-0.25 ms per step, same box,
 // two repetitions; raising it before the tap's B-fragment loads instead: the same).  -DSGG_MFMA_PRIO=0 builds without.

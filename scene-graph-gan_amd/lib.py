@@ -149,8 +149,8 @@ DEFAULT_OPTIONS = {
     "halo_pc": True,
     # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = per layer and per KIND of
     # encoder pass (forward-only / followed by a backward) where trunk.ln_fusion_pays' measured cost model says it pays
-    # (trunk._plan_ln_fusion: 28 of the 44 apply passes of a step at configs[1]); 2 = wherever the kernels allow (slower:
-    # DESIGN.md); 0 = never
+    # (trunk._plan_ln_fusion: with pre-split activations 16 of the 44 apply passes of a step at configs[1] run as prologues, 28 as
+    # standalone passes - DESIGN.md "The LN prologue"); 2 = wherever the kernels allow (slower: DESIGN.md); 0 = never
     "ln_fusion": 1,
     # True: the LayerNorm kernels write their outputs pre-split for the convolutions that consume them (trunk._plan_s16; fp16 modes)
     "presplit": True,

@@ -23,4 +23,13 @@ for d, cname in (("calib_f", "FETCH_SIZE"), ("calib_w", "WRITE_SIZE")):
                 acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print("%-11s %-34s launches %d  KiB per launch %s  factor %s" % (cname, k, len(v), ["%.0f" % x for x in v], ["%.3f" % (x * 1024 / BYTES) for x in v]))
+print("# kernel durations (kernel trace of the FETCH_SIZE pass): the same bytes in how many microseconds")
+dur = defaultdict(list)
+for f in glob.glob(os.path.join(R, "gpurun_out", "calib_f", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(dur.items()):
+    if k.startswith(("r_", "w_", "void w_")):
+        med = sorted(v)[len(v) // 2]
+        print("%-34s us %s   %.2f TB/s" % (k, ["%.1f" % x for x in v], BYTES / med / 1e6))
 PY

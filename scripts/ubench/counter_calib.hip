@@ -8,6 +8,7 @@
 //                             of one 32-channel group of a pre-split tensor (4 lanes x 16 B per pixel; the pixel pitch is 512 B),
 //                             the other plane of the same 128-byte groups by the next instruction
 //   writes  w_stream_nt       16-byte nontemporal stores, lane l writes base + 16 l
+//           w_stream_plain    the same with default-policy stores
 //           w_quad_nt         the producer / consumer kernel's epilogue: a wave owns 64 pixels (an 8x8 block) x 64 channels of a
 //                             128-channel NHWC tensor; per store instruction 4 lanes cover 64 contiguous bytes of one pixel (16
 //                             channels), 16 pixels per instruction; the neighbouring 64 bytes of the same 128-byte line follow
@@ -29,7 +30,7 @@ static const size_t BYTES = (size_t)B_ * H_ * W_ * N_ * 4;
 
 __device__ __forceinline__ void dma16(v4i rs, unsigned lds_addr, unsigned voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
-               : "memory", "m0");
+               : "memory");
 }
 __device__ __forceinline__ v4i rsrc(const void* base, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(base);
@@ -83,6 +84,9 @@ __global__ __launch_bounds__(256) void w_stream_nt(f4* __restrict__ dst, size_t 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
     __builtin_nontemporal_store(f4{1.f, 2.f, 3.f, 4.f}, dst + i);
 }
+__global__ __launch_bounds__(256) void w_stream_plain(f4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = f4{1.f, 2.f, 3.f, 4.f};
+}
 
 // a wave = one 8x8 block x one 64-column half; 16 store instructions (i = row pair, j = 16-column group) as the epilogue issues them
 template <bool NT>
@@ -119,6 +123,7 @@ int main() {
     hipLaunchKernelGGL(r_stream_dma, grid, blk, 0, 0, a, (unsigned)BYTES, sink);
     hipLaunchKernelGGL(r_gather_dma, grid, blk, 0, 0, a, (unsigned)BYTES, sink);
     hipLaunchKernelGGL(w_stream_nt, grid, blk, 0, 0, (f4*)a, n16);
+    hipLaunchKernelGGL(w_stream_plain, grid, blk, 0, 0, (f4*)a, n16);
     hipLaunchKernelGGL(w_quad<true>, grid, blk, 0, 0, a);
     hipLaunchKernelGGL(w_quad<false>, grid, blk, 0, 0, a);
   }
