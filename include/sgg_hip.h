@@ -93,7 +93,11 @@ int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, con
                         int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int precision, int w_split_layout,
                         const float* amax_x, const float* amax_w, float* tile_stats, const float* ln_stats, const float* ln_gamma,
                         const float* ln_beta, int operand_format, void* stream);
-/* operand_format (sgg_conv2d_nhwc_fwd / _dgrad: 0 or 1; _wgrad: bit 0 = x, bit 1 = dy): 1 = the operand is a PRE-SPLIT tensor as
+/* operand_format of sgg_conv2d_nhwc_fwd, bits 8 .. 13 (launch hint, 0 = none): the persistent resident kernels (w_split_layout
+ * 1 .. 4) occupy at most that many of an XCD's 32 CUs instead of all of them - for a forward pass that runs on its own HIP stream
+ * beside another stream's chain of short, latency-critical launches (the recurrent heads), which then find free CUs at once.  The
+ * work decomposition (tiles, products, summation orders) does not depend on it: results are bit-identical.
+ * operand_format bit 0 (sgg_conv2d_nhwc_fwd / _dgrad: 0 or 1; _wgrad: bit 0 = x, bit 1 = dy): 1 = the operand is a PRE-SPLIT tensor as
  * sgg_layernorm_hwc_elu_fwd / _bwd write it with out_format 1 - same shape and bytes as the f32 tensor, every aligned group of 32
  * channels (128 B) holding the 32 leading fp16 pieces (64 B) then the 32 residual pieces of x * 2^e, e from the tensor's amax word
  * (which must be the word the producer used).  The kernel then stages the operand without splitting it again (bit-identical

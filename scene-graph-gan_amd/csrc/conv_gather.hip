@@ -888,6 +888,10 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
                                    int precision, int w_split_layout, const float* amax_x, const float* amax_w, float* tile_stats,
                                    const float* ln_stats, const float* ln_gamma, const float* ln_beta, int operand_format, void* stream) {
   SGG_CHECK_ARG(x && w && bias && y, "sgg_conv2d_nhwc_fwd: null pointer");
+  // bits 8 .. 13: launch hint for the persistent kernels - occupy at most this many of an XCD's 32 CUs (0 = all; include/sgg_hip.h)
+  const int cu_cap = (operand_format >> 8) & 63;
+  SGG_CHECK_ARG((operand_format & ~0x3f01) == 0 && cu_cap <= 32, "sgg_conv2d_nhwc_fwd: operand_format: bit 0 = pre-split x, bits 8 .. 13 = CUs per XCD (<= 32)");
+  operand_format &= 1;
   SGG_CHECK_ARG(operand_format == 0 || (operand_format == 1 && sgg_prec_half(precision) && w_split_layout >= 1 && w_split_layout <= 4 &&
                                         !ln_stats && Cin != 3),
                 "sgg_conv2d_nhwc_fwd: a pre-split (S16) x needs precision 1 / 2, a resident kernel (w_split_layout 1 .. 4) and no LN prologue");
@@ -926,6 +930,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     sgg_halo_dense_strides(h);
     h.frag16 = w_split_layout == 4;
     h.src_s16 = operand_format & 1;
+    h.cu_cap = cu_cap;
     SGG_CHECK_ARG((size_t)B * Hi * Wi * Cin * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_fwd: input exceeds 2 GiB");
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(halo)");
@@ -946,6 +951,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     h.in_rs = 2 * Wi * Cin; h.in_ps = 2 * Cin; h.in_cA = Wi * Cin; h.in_cB = Cin;     // chunk (qy, qx): x[2a + qy][2c + qx][0..32)
     h.ln_nc = Cin;
     h.src_s16 = operand_format & 1;
+    h.cu_cap = cu_cap;
     sgg_halo_launch(h, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(s2d)");
     return SGG_OK;
@@ -964,6 +970,7 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
     q.src_bytes = (unsigned)((size_t)B * Hi * Wi * Cin * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
     q.src_s16 = operand_format & 1;
+    q.cu_cap = cu_cap;
     sgg_s2_launch(q, 0, precision, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_fwd(s2)");
     return SGG_OK;
@@ -1055,6 +1062,7 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     q.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * sizeof(float));
     q.w_bytes = (unsigned)((size_t)25 * Cin * Cout * sizeof(float));
     q.src_s16 = operand_format & 1;
+    q.cu_cap = 0;
     sgg_s2_launch(q, 1, precision, (hipStream_t)stream);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_dgrad(s2)");
     return SGG_OK;

@@ -31,13 +31,17 @@ struct HaloParams {
   int ln_nc;              // LN prologue: real channels of the source (a power of two: C, or 32 for the space-to-depth view)
   int frag16;             // 1: wfrag holds the fragments of the K = 32 MFMA shape (w_split_layout 4): the producer / consumer kernel
   int src_s16;            // 1: src is a pre-split ("S16") tensor of the LayerNorm kernels (split16.h): staged without arithmetic
+  int cu_cap;             // > 0: the persistent workgroups occupy at most this many of an XCD's 32 CUs (launch hint of the forward entry point)
 };
+// CUs of an XCD a persistent launch may occupy
+inline int sgg_persist_cus(int cu_cap) { return (cu_cap > 0 && cu_cap < SGG_PERSIST_CUS_PER_XCD) ? cu_cap : SGG_PERSIST_CUS_PER_XCD; }
 inline void sgg_halo_dense_strides(HaloParams& h) {
   h.in_rs = h.W * h.C; h.in_ps = h.C; h.in_cA = 64; h.in_cB = 32;
   h.out_rs = h.W * h.N; h.out_ps = h.N; h.out_nA = 64; h.out_nB = 32;
   h.ln_nc = h.C;
   h.frag16 = 0;
   h.src_s16 = 0;
+  h.cu_cap = 0;
 }
 
 // 1 if the halo kernel serves a 3x3 / stride-1 convolution over an H x W grid in this precision
@@ -113,6 +117,7 @@ struct S2Params {
   int src_s16;            // 1: src is a pre-split ("S16") tensor (split16.h)
   int ksplit;             // 1, or 2: two workgroups per (band, n-tile), each contracting half of the channel chunks and ADDING its
                           // partial into the zeroed output (a + b = b + a: still deterministic); set by sgg_s2_launch
+  int cu_cap;             // as HaloParams::cu_cap
 };
 // 1 if the band-resident kernel serves this 5x5 / stride-2 / SAME convolution (Hi, Wi = the full-resolution grid, both even;
 // C = contraction channels, N = output channels of the direction asked for)

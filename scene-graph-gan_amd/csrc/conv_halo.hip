@@ -642,7 +642,7 @@ void sgg_halo_launch(const HaloParams& p_, int precision, hipStream_t st) {
   do {                                                                                                       \
     const int mtiles = sgg_cdiv(p.nblk, NB), ntn = p.N / BN;                                                 \
     int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       /* (tile, n-tile) pairs an XCD owns */                    \
-    const int cap = SGG_PERSIST_CUS_PER_XCD * 8 / (WGM * WGN);   /* eight resident waves on each of its (32) CUs */     \
+    const int cap = sgg_persist_cus(p.cu_cap) * 8 / (WGM * WGN);   /* eight resident waves on each of its (32) CUs */   \
     int gx = per_xcd < cap ? per_xcd : cap;                                                                  \
     gx = sgg_cdiv(gx, ntn) * ntn;                                                                            \
     p.gx = gx;                                                                                               \

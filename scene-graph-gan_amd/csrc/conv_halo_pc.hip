@@ -587,7 +587,8 @@ void sgg_halo_pc_launch(const HaloParams& p_, int precision, hipStream_t st) {
   HaloParams p = p_;
   const int mtiles = sgg_cdiv(p.nblk, PC_NB), ntn = p.N / 128;
   int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       // (tile, n-tile) pairs an XCD owns
-  int gx = per_xcd < SGG_PERSIST_CUS_PER_XCD ? per_xcd : SGG_PERSIST_CUS_PER_XCD;          // one workgroup on each of its (32) CUs
+  const int cus = sgg_persist_cus(p.cu_cap);
+  int gx = per_xcd < cus ? per_xcd : cus;          // one workgroup on each of its (32) CUs
   gx = sgg_cdiv(gx, ntn) * ntn;
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx)), blk(512);

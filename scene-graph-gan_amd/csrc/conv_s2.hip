@@ -597,7 +597,7 @@ void sgg_s2_launch(const S2Params& p_, int dgrad, int precision, hipStream_t st)
     (void)hipMemsetAsync(p.out, 0, (size_t)(dgrad ? 4 : 1) * p.M * p.N * sizeof(float), st);
   const int ntn = (p.N / bn) * p.ksplit;
   p.nbands = sgg_cdiv(p.M, 32 * mt);
-  const int slots = wide ? SGG_PERSIST_CUS_PER_XCD : 2 * SGG_PERSIST_CUS_PER_XCD;      // resident workgroups per XCD (32 CUs)
+  const int slots = (wide ? 1 : 2) * sgg_persist_cus(p.cu_cap);      // resident workgroups per XCD (32 CUs)
   int per_xcd = sgg_cdiv(p.nbands, 8) * ntn;       // (band, n-tile, channel half) items an XCD owns
   int gx = per_xcd < slots ? per_xcd : slots;
   gx = sgg_cdiv(gx, ntn) * ntn;

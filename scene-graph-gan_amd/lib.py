@@ -165,6 +165,15 @@ DEFAULT_OPTIONS = {
     # two-stream schedule: 1 = G's encoder forward of the update after a critic update starts on a stream of its own as soon as that
     # critic update's G head has run, beside its heads and encoder backward (step.GanStep._g_early_stream)
     "g_early": 1,
+    # ... and while it runs there its persistent convolution kernels occupy only this many of an XCD's 32 CUs (0 = all): the critic's
+    # recurrent heads - a chain of short launches on the critical path - then find free CUs at once instead of waiting for a resident
+    # workgroup of G's forward to finish its tile.  The convolutions lose nothing on 28 of 32 CUs (every persistent kernel capped at
+    # 28: +0.25 ms per step only, profiles/r05_persistent_cu_cap_ab.log); 28 here: 42.75 / 42.80 against 43.04 / 42.97 ms per step, on
+    # another box 44.02 / 44.07 against 44.32 / 44.18; 30, 26, 24, 20: equal to none (profiles/r05_early_forward_cu_cap_ab*.log).
+    # Tiles, products and summation orders are unchanged: bit-identical results (tests/test_concurrency_gpu.py)
+    "g_early_cus": 28,
+    "d_side_cus": 0,      # the same for D's encoder forward on the side stream (beside G's forward and G's head)
+    "fwd_cus": 0,         # the same for every encoder forward (16: G's and D's forwards of an update on disjoint halves of the chip)
     # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward /
     # never fuse in passes with backward
     "ln_fusion_skip": (),
@@ -402,11 +411,12 @@ class HipKernels:
                                                          8 if dma and n_out % 256 == 0 and -(-m_positions // 224) * (n_out // 256) > 128 else 4)
 
     def conv_fwd(self, x, w_hwio, w_fwd, bias, y, stride, w_split=None, amax_x=None, amax_w=None, tile_stats=None, w_split_layout=0,
-                 ln=None, x_s16=False):
+                 ln=None, x_s16=False, cu_cap=0):
         """y = conv2d_same(x, w) + bias. w_fwd: HWOI transpose of w_hwio (or w_hwio itself when Cin == 3).
         ln = (stats [B,2], gamma, beta): x is the producing layer's PRE-LayerNorm output; the kernel applies LN + ELU while staging
         (halo-resident kernel only; amax_x = the word ln_finalize published).
-        x_s16: x is a pre-split tensor (ln_elu_fwd(..., out_s16=True); amax_x = the word that call published)."""
+        x_s16: x is a pre-split tensor (ln_elu_fwd(..., out_s16=True); amax_x = the word that call published).
+        cu_cap (1 .. 31): the persistent kernels occupy at most that many of an XCD's 32 CUs (operand_format bits 8 .. 13)."""
         self._dev(x, w_fwd, bias, y)
         ln_s, ln_g, ln_b = ln if ln is not None else (None, None, None)
         self._dev(ln_s, ln_g, ln_b)
@@ -425,7 +435,8 @@ class HipKernels:
             nb = 4.0 * (x.numel() + y.numel())      # conv1_1 (K = 27) is HBM-bound: the image read once, y written once
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_fwd(
             _p(x), _p(w_fwd), _p(w_split), _p(bias), _p(y), *d, self.conv_precision, w_split_layout, _p(amax_x), _p(amax_w),
-            _p(tile_stats), _p(ln_s), _p(ln_g), _p(ln_b), int(bool(x_s16)), self._stream()), nb), "sgg_conv2d_nhwc_fwd")
+            _p(tile_stats), _p(ln_s), _p(ln_g), _p(ln_b), int(bool(x_s16)) | ((int(cu_cap) & 63) << 8), self._stream()), nb),
+            "sgg_conv2d_nhwc_fwd")
 
     def conv_dgrad(self, dy, w_hwio, dx, stride, w_split=None, amax_dy=None, amax_w=None, w_split_layout=0, dy_s16=False):
         """dy_s16: dy is a pre-split tensor (ln_elu_bwd(..., out_s16=True); amax_dy = the word that call published)."""

@@ -176,8 +176,10 @@ class GanStep:
         else:
             keep = for_backward or self._g_reuse_armed
             if early is not None:        # (the caller made `early` wait for everything this forward depends on)
+                cap = int(getattr(self.K, "g_early_cus", 0))
+                kw = {"cu_cap": cap} if cap else {}
                 with torch.cuda.stream(early):
-                    ctx = G.trunk.forward(images, keep) if keep is False else G.trunk.forward(images)
+                    ctx = G.trunk.forward(images, keep, **kw) if keep is False else G.trunk.forward(images, **kw)
                     G.head.precompute(ctx)
                 torch.cuda.current_stream().wait_stream(early)
             else:
@@ -202,11 +204,13 @@ class GanStep:
             return ctx
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
+        cap = int(getattr(self.K, "d_side_cus", 0))      # (option d_side_cus: as g_early_cus, for D's forward beside G's forward and head)
+        kw = {"cu_cap": cap} if cap else {}
         with torch.cuda.stream(self.side):
             D.finish_update()
             if zero_grads:
                 D.zero_grads()
-            ctx = D.trunk.forward(images, for_backward) if for_backward is False else D.trunk.forward(images)
+            ctx = D.trunk.forward(images, for_backward, **kw) if for_backward is False else D.trunk.forward(images, **kw)
             D.head.precompute(ctx)
         return ctx
 

@@ -317,10 +317,14 @@ class Trunk:
         self._plan_ln_fusion()
         self._plan_s16()
 
-    def forward(self, images, for_backward=True):
+    def forward(self, images, for_backward=True, cu_cap=0):
         """images [B,S,S,3] NHWC fp32, already standardised (train.py:172) -> downsampled as ctx [B, L, 512].
         for_backward=False (G in the critic update, D in the generator update: no encoder backward follows): LayerNorm + ELU of a
-        layer may be applied by the consuming convolution's patch staging instead of a pass of its own (K.ln_fusion = 1)."""
+        layer may be applied by the consuming convolution's patch staging instead of a pass of its own (K.ln_fusion = 1).
+        cu_cap (1 .. 31): launch hint - the persistent convolution kernels of this pass occupy at most that many of an XCD's 32 CUs
+        (a forward that runs beside another stream's latency-critical chain: step.GanStep, option g_early_cus)."""
+        cu_cap = cu_cap or int(getattr(self.K, "fwd_cus", 0))      # (option fwd_cus: the same hint for every encoder forward)
+        cap = {"cu_cap": int(cu_cap)} if cu_cap else {}
         assert tuple(images.shape) == (self.B, self.S, self.S, 3), images.shape
         K = self.K
         if self._wver != getattr(self.arena, "version", 0):
@@ -343,14 +347,14 @@ class Trunk:
                                    and (lay["cin"] == 3 or lay.get("tstats_mode") == (K.conv_precision, lay["ws_layout"]))) else None
             if ln_in is not None:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1), self._am(2, j), ts,
-                           lay["ws_layout"], ln=ln_in)
+                           lay["ws_layout"], ln=ln_in, **cap)
             elif x_s16:
                 assert ws is not None
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1), self._am(2, j), ts, lay["ws_layout"],
-                           x_s16=True)
+                           x_s16=True, **cap)
             elif ws is not None or self._f16() or ts is not None:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"], ws, self._am(0, j - 1) if j else None, self._am(2, j), ts,
-                           lay["ws_layout"] if ws is not None else 0)
+                           lay["ws_layout"] if ws is not None else 0, **cap)
             else:
                 K.conv_fwd(x, lay["w"], lay["w_fwd"], lay["b"], lay["y"], lay["s"])
             ln_in = None

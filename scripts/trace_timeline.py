@@ -61,3 +61,34 @@ for a, b, n, q in win:
 print("  kernels resident while no matrix kernel is (ms per step, summed per kernel; overlapping each other is counted twice):")
 for n, v in sorted(acc.items(), key=lambda kv: -kv[1])[:25]:
     print("    %-72s %6.3f" % (n, v / 1e6 / nsteps))
+
+# ---- the matrix-idle intervals of ONE step (the last one), longest first: where in the schedule the matrix pipe has nothing -------
+step_lo = rows[adam[-3]][1] if len(adam) > 3 else lo
+gaps = []
+prev = step_lo
+for c, d in um:
+    if d <= step_lo:
+        continue
+    if c > prev:
+        gaps.append((prev, c))
+    prev = max(prev, d)
+if hi > prev:
+    gaps.append((prev, hi))
+print("  matrix-idle intervals of the last step (%.2f ms in %d intervals); the 14 longest, in time order, with the kernels inside:"
+      % (sum(b - a for a, b in gaps) / 1e6, len(gaps)))
+top = sorted(sorted(gaps, key=lambda g: g[0] - g[1])[:14])
+for a, b in top:
+    inside = defaultdict(lambda: [0, 0.0])
+    for s, e, n, q in win:
+        if e > a and s < b and not mfma(n):
+            k = n.replace("void ", "").split("(")[0][:44]
+            inside[k][0] += 1
+            inside[k][1] += (min(e, b) - max(s, a)) / 1e3
+    busy = length(union([(max(s, a), min(e, b)) for s, e, n, q in win if e > a and s < b and not mfma(n)])) / 1e3
+    # the matrix kernels on either side
+    before = [n for s, e, n, q in win if mfma(n) and e <= a + 1]
+    after = [n for s, e, n, q in win if mfma(n) and s >= b - 1]
+    name = lambda n: n.replace("void ", "").split("(")[0][:40]
+    print("    +%7.3f ms  %7.1f us (busy %6.1f)  after %-40s before %-40s : %s"
+          % ((a - step_lo) / 1e6, (b - a) / 1e3, busy, name(before[-1]) if before else "-", name(after[0]) if after else "-",
+             ", ".join("%s x%d %.0fus" % (k, v[0], v[1]) for k, v in sorted(inside.items(), key=lambda kv: -kv[1][1])[:5])))
