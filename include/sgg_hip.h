@@ -164,6 +164,25 @@ int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const float* gamm
                               float* pq /* out_format 1: two words, zeroed by the caller, for the maxima the bound is made of */,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* The REDUCTION half of sgg_layernorm_hwc_elu_bwd without its apply pass, for a consumer that computes dy itself
+ * (sgg_conv2d_nhwc_wgrad_c3_ln below): the partial sums go to `workspace` exactly as sgg_layernorm_hwc_elu_bwd leaves them (dgamma /
+ * dbeta / dbias_prev: all NULL and sgg_layernorm_hwc_bwd_finalize later, or all given), and means [B][2] receives the two per-sample
+ * means of the backward, (mean dxhat, mean dxhat * xhat), bit-identical to the values the apply pass derives.  Whole planes only. */
+int sgg_layernorm_hwc_elu_bwd_sums(const float* y, const float* da, const float* gamma, const float* beta, const float* stats,
+                                   float* means, float* dgamma, float* dbeta, float* dbias_prev, int B, int HW, int C, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+/* conv1_1's filter gradient FUSED with the apply half of the LayerNorm backward of its output (generator_with_attention.py:29-30
+ * under optimizer.minimize, train.py:265-266): dW [3][3][3][32] = Conv2DBackpropFilter(x, dy) with
+ *   dy = rstd * (da * ELU'(n) * gamma - m1 - xhat * m2),  xhat = (y - mean) * rstd,  n = xhat * gamma + beta
+ * computed from (y, da) [B][H][W][32] inside the kernel - conv1_1's filter gradient is the only consumer of that dy (no image
+ * gradient is taken, the bias gradient comes from the LayerNorm reductions), so it is never written: one read of y and da replaces
+ * the apply pass (read y, read da, write dy) and the filter gradient's read of dy.  stats [B][2] = (mean, rstd) of the forward,
+ * means [B][2] from sgg_layernorm_hwc_elu_bwd_sums; exact f32 MFMA arithmetic as sgg_conv2d_nhwc_wgrad with Cin == 3; workspace as
+ * sgg_conv2d_nhwc_wgrad_workspace_bytes(B, H, W, 3, H, W, 32, 3, 3). */
+int sgg_conv2d_nhwc_wgrad_c3_ln(const float* x, const float* y, const float* da, const float* gamma, const float* beta,
+                                const float* stats, const float* means, float* dw, int B, int H, int W, int pad_t, int pad_l,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* dgamma == dbeta == NULL in sgg_layernorm_hwc_elu_bwd DEFERS the parameter-gradient reductions (dgamma, dbeta, dbias_prev): the
  * partial sums stay in `workspace` (give every layer its own), and one launch of sgg_layernorm_hwc_bwd_finalize reduces up to 16
  * layers at once (an encoder backward: eleven 20-microsecond launches off its critical path). */

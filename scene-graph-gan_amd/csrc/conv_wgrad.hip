@@ -490,9 +490,26 @@ __device__ __forceinline__ void c3w_lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// LNB (round 5): dy is not read - it is COMPUTED here, from the operands of the LayerNorm backward of conv1_1's output (the
+// pre-LayerNorm y, the gradient da of the activation, gamma, beta, the per-sample (mean, rstd) and the two per-sample means m1 =
+// mean(dxhat), m2 = mean(dxhat * xhat) of sgg_layernorm_hwc_elu_bwd_sums), with the arithmetic of ln_bwd_apply_kernel
+// (csrc/layernorm.hip):  dy = rstd * (da * ELU'(n) * gamma - m1 - xhat * m2),  xhat = (y - mean) * rstd,  n = xhat * gamma + beta.
+// conv1_1's filter gradient is the ONLY consumer of that dy (no image gradient is needed, the bias gradient comes from the
+// LayerNorm reductions), so the LayerNorm backward's apply pass - 411 MB read twice and 411 MB written at batch 64, on the tail of
+// every encoder backward where nothing else can run - and this kernel's 411 MB read of dy become ONE read of y and da.
+struct C3LnArgs {
+  const float* y;
+  const float* da;
+  const float* gamma;
+  const float* beta;
+  const float* stats;      // [B][2] (mean, rstd)
+  const float* means;      // [B][2] (m1, m2)
+};
+// (LNB: 64 more prefetch registers - y beside da - do not fit three workgroups per CU without spilling: two)
+template <bool LNB>
+__global__ __launch_bounds__(256, LNB ? 2 : 3) void conv_c3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ slabs, int H, int W, int pt, int pl,
-                                                               int tiles_x, int tiles_y, int ntiles, int tiles_per_wg) {
+                                                               int tiles_x, int tiles_y, int ntiles, int tiles_per_wg, C3LnArgs ln) {
   constexpr int COUT = 32, PITCH = 36, PLANE = 10 * PITCH;
   __shared__ float patch[3 * PLANE];
   __shared__ float red[4 * 32 * 32];
@@ -507,6 +524,16 @@ __global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __re
   const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
   // the NEXT tile's patch pixels and this wave's dy values are fetched into registers while this tile is computed
   float pv[2][3], dvn[2][16];
+  // LNB: the prefetched y values (dvn then holds da), the validity of the lane's eight (row, column group) items, the tile's sample
+  // constants, and this lane's four channels of gamma / beta
+  float yvn[LNB ? 2 : 1][LNB ? 16 : 1];
+  int okn = 0;
+  float cstn[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gmv = {0.f, 0.f, 0.f, 0.f}, btv = gmv;
+  if constexpr (LNB) {
+    gmv = *reinterpret_cast<const f32x4*>(ln.gamma + (i & ~3));
+    btv = *reinterpret_cast<const f32x4*>(ln.beta + (i & ~3));
+  }
   auto load_tile = [&](int t_) __attribute__((always_inline)) {
     const int tx_ = t_ % tiles_x, t2_ = t_ / tiles_x;
     const int ty_ = t2_ % tiles_y, b_ = t2_ / tiles_y;
@@ -526,16 +553,29 @@ __global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __re
     // 16-byte loads: lane (h, g = i >> 2, k = i & 3) fetches dy of pixel (row 2 wave + m, column 8 q + 4 h + k), channels 4 g .. 4 g + 3
     // (zeros outside the image: they contribute nothing); the quad transpose at the point of use turns them into this lane's
     // channel i at columns 8 q + 4 h + (0 .. 3) - the B operands of MFMAs (q, j), whose two pixels are columns 8 q + j and 8 q + 4 + j
+    if constexpr (LNB) {
+      okn = 0;
+      const int bb = live ? b_ : 0;
+      cstn[0] = ln.stats[2 * bb]; cstn[1] = ln.stats[2 * bb + 1]; cstn[2] = ln.means[2 * bb]; cstn[3] = ln.means[2 * bb + 1];
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int yy = y0_ + 2 * wave + m;
-      const float* drow = dy + ((size_t)(b_ * H + yy) * W + x0_ + 4 * h + (i & 3)) * COUT + (i & ~3);
+      const size_t roff = ((size_t)(b_ * H + yy) * W + x0_ + 4 * h + (i & 3)) * COUT + (i & ~3);
+      const float* drow = (LNB ? ln.da : dy) + roff;
       const int cmax = W - x0_ - 4 * h - (i & 3);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (live && yy < H && 8 * q < cmax) v = *reinterpret_cast<const f32x4*>(drow + (size_t)(8 * q) * COUT);
+        const bool ok = live && yy < H && 8 * q < cmax;
+        if (ok) v = *reinterpret_cast<const f32x4*>(drow + (size_t)(8 * q) * COUT);
         dvn[m][4 * q] = v[0]; dvn[m][4 * q + 1] = v[1]; dvn[m][4 * q + 2] = v[2]; dvn[m][4 * q + 3] = v[3];
+        if constexpr (LNB) {
+          f32x4 u = {0.f, 0.f, 0.f, 0.f};
+          if (ok) u = *reinterpret_cast<const f32x4*>(ln.y + roff + (size_t)(8 * q) * COUT);
+          yvn[m][4 * q] = u[0]; yvn[m][4 * q + 1] = u[1]; yvn[m][4 * q + 2] = u[2]; yvn[m][4 * q + 3] = u[3];
+          okn |= (int)ok << (4 * m + q);
+        }
       }
     }
   };
@@ -557,7 +597,21 @@ __global__ __launch_bounds__(256, 3) void conv_c3_wgrad_kernel(const float* __re
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        dv[m][4 * q] = dvn[m][4 * q]; dv[m][4 * q + 1] = dvn[m][4 * q + 1]; dv[m][4 * q + 2] = dvn[m][4 * q + 2]; dv[m][4 * q + 3] = dvn[m][4 * q + 3];
+        if constexpr (LNB) {
+          // dy of this lane's pixel (row 2 wave + m, column 8 q + 4 h + (i & 3)), channels 4 (i >> 2) .. + 3: ln_bwd_apply_kernel's arithmetic
+          const float mean = cstn[0], rstd = cstn[1], m1 = cstn[2], m2 = cstn[3];
+          const bool ok = (okn >> (4 * m + q)) & 1;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float xh = (yvn[m][4 * q + c] - mean) * rstd;
+            const float n = xh * gmv[c] + btv[c];
+            const float dn = dvn[m][4 * q + c] * (n > 0.f ? 1.f : __expf(n));
+            const float o = rstd * (dn * gmv[c] - m1 - xh * m2);
+            dv[m][4 * q + c] = ok ? o : 0.f;          // (outside the image: no pixel, no contribution)
+          }
+        } else {
+          dv[m][4 * q] = dvn[m][4 * q]; dv[m][4 * q + 1] = dvn[m][4 * q + 1]; dv[m][4 * q + 2] = dvn[m][4 * q + 2]; dv[m][4 * q + 3] = dvn[m][4 * q + 3];
+        }
         sgg_quad_transpose4(dv[m][4 * q], dv[m][4 * q + 1], dv[m][4 * q + 2], dv[m][4 * q + 3], lane);
       }
     c3w_lds_barrier();
@@ -699,8 +753,8 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
                            "stride 2 on grids divisible by 8, precision 2 or 3, algo 0)");
   if (Cin == 3) {
     SGG_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && Cout == 32, "sgg_conv2d_nhwc_wgrad: Cin=3 path needs 3x3 s1 Cout=32");
-    hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, Hi, Wi, pad_t, pad_l,
-                       sgg_cdiv(Wo, 32), sgg_cdiv(Ho, 8), pl.tiles, pl.chunk);
+    hipLaunchKernelGGL(conv_c3_wgrad_kernel<false>, dim3(pl.nsplit), dim3(256), 0, st, x, dy, (float*)workspace, Hi, Wi, pad_t, pad_l,
+                       sgg_cdiv(Wo, 32), sgg_cdiv(Ho, 8), pl.tiles, pl.chunk, C3LnArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3)");
     launch_slab_reduce((const float*)workspace, dw, nout / 4, pl.nsplit, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(c3 reduce)");
@@ -751,5 +805,29 @@ extern "C" int sgg_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw,
     launch_slab_reduce((const float*)workspace, dw, nout / 4, pl.nsplit, st);
     SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad(reduce)");
   }
+  return SGG_OK;
+}
+
+// conv1_1's filter gradient FUSED with the apply half of the LayerNorm backward of its output (conv_c3_wgrad_kernel<true>):
+//   dW = Conv2DBackpropFilter(x, dy),  dy = LayerNormBackward(y, da) of tf.contrib.layers.layer_norm(activation_fn=elu)
+// (architectures/generator_with_attention.py:29-30 under optimizer.minimize, train.py:265-266).  means [B][2] comes from
+// sgg_layernorm_hwc_elu_bwd_sums on the same (y, da); dy itself is never materialised.
+extern "C" int sgg_conv2d_nhwc_wgrad_c3_ln(const float* x, const float* y, const float* da, const float* gamma, const float* beta,
+                                           const float* stats, const float* means, float* dw, int B, int H, int W, int pad_t, int pad_l,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  SGG_CHECK_ARG(x && y && da && gamma && beta && stats && means && dw, "sgg_conv2d_nhwc_wgrad_c3_ln: null pointer");
+  SGG_CHECK_ARG(B > 0 && H > 0 && W > 0 && pad_t == 1 && pad_l == 1, "sgg_conv2d_nhwc_wgrad_c3_ln: bad dims (3x3 stride 1, SAME padding)");
+  SGG_CHECK_ARG((long long)B * H * W * 32 < (1LL << 31), "sgg_conv2d_nhwc_wgrad_c3_ln: tensor exceeds 2^31 elements");
+  const WgradPlan pl = wgrad_plan(B, H, W, 3, 32, 3, 3);
+  if (!workspace || workspace_bytes < pl.ws_bytes) {
+    sgg_set_error("sgg_conv2d_nhwc_wgrad_c3_ln: workspace too small (%zu < %zu)", workspace_bytes, pl.ws_bytes);
+    return SGG_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv_c3_wgrad_kernel<true>, dim3(pl.nsplit), dim3(256), 0, st, x, (const float*)nullptr, (float*)workspace, H, W, pad_t,
+                     pad_l, sgg_cdiv(W, 32), sgg_cdiv(H, 8), pl.tiles, pl.chunk, C3LnArgs{y, da, gamma, beta, stats, means});
+  SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad_c3_ln");
+  launch_slab_reduce((const float*)workspace, dw, 27LL * 32 / 4, pl.nsplit, st);
+  SGG_LAUNCH_CHECK("sgg_conv2d_nhwc_wgrad_c3_ln(reduce)");
   return SGG_OK;
 }

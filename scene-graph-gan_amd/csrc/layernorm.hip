@@ -741,6 +741,53 @@ extern "C" int sgg_layernorm_hwc_elu_bwd(const float* y, const float* da, const 
   return SGG_OK;
 }
 
+// The two per-sample means of the backward, as every workgroup of ln_bwd_apply_kernel derives them from the partial sums (the same
+// strided per-thread sums, the same block reduction, the same division: bit-identical values): means[b] = (mean dxhat, mean dxhat * xhat).
+__global__ __launch_bounds__(256) void ln_bwd_means_kernel(const float* __restrict__ sspart, float* __restrict__ means, int G, float n) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float a1 = 0.f, a2 = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) {
+    a1 += sspart[((size_t)b * G + i) * 2 + 0];
+    a2 += sspart[((size_t)b * G + i) * 2 + 1];
+  }
+  const float m1 = block_sum_256(a1, red) / n;
+  const float m2 = block_sum_256(a2, red) / n;
+  if (threadIdx.x == 0) {
+    means[2 * b + 0] = m1;
+    means[2 * b + 1] = m2;
+  }
+}
+
+// The REDUCTION half of sgg_layernorm_hwc_elu_bwd without its apply pass, for a consumer that computes dy itself
+// (sgg_conv2d_nhwc_wgrad_c3_ln: conv1_1's filter gradient, the only consumer of the first LayerNorm's dy): the partial sums go to
+// `ws` exactly as sgg_layernorm_hwc_elu_bwd leaves them (dgamma / dbeta / dbias_prev: pass NULL and reduce them later with
+// sgg_layernorm_hwc_bwd_finalize, or pass all of them), and means [B][2] receives (mean dxhat, mean dxhat * xhat) per sample.
+// Whole planes only (no valid region).
+extern "C" int sgg_layernorm_hwc_elu_bwd_sums(const float* y, const float* da, const float* gamma, const float* beta, const float* stats,
+                                              float* means, float* dgamma, float* dbeta, float* dbias_prev, int B, int HW, int C, void* ws,
+                                              size_t ws_bytes, void* stream) {
+  SGG_CHECK_ARG(y && da && gamma && beta && stats && means && (!dgamma == !dbeta), "sgg_layernorm_hwc_elu_bwd_sums: null pointer");
+  int rc = ln_check("sgg_layernorm_hwc_elu_bwd_sums", B, HW, C, ws_bytes, ws);
+  if (rc) return rc;
+  LnMask mk;
+  float nvalid;
+  if ((rc = ln_mask("sgg_layernorm_hwc_elu_bwd_sums", HW, C, 0, 0, 0, 0, 0, mk, nvalid))) return rc;
+  const LnGeom g = ln_geom(B, HW, C);
+  hipStream_t st = (hipStream_t)stream;
+  float* sspart = (float*)ws + (size_t)B * g.G * SGG_TS;
+  float* chpart = sspart + (size_t)B * g.G * 2;
+  const size_t sm = (size_t)(2 * B + LNF_BL * 32 * 3) * sizeof(float);
+  hipLaunchKernelGGL(ln_bwd_partial_kernel<false>, dim3(g.G, B), dim3(256), 0, st, y, da, gamma, beta, stats, sspart, chpart,
+                     (float*)nullptr, g.N, C, g.G, g.cpg, mk);
+  if (dgamma)
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(sgg_cdiv(C, 32)), dim3(1024), sm, st, (const float*)sspart,
+                       (const float*)chpart, gamma, stats, dgamma, dbeta, dbias_prev, B, C, g.G, HW);
+  hipLaunchKernelGGL(ln_bwd_means_kernel, dim3(B), dim3(256), 0, st, (const float*)sspart, means, g.G, (float)g.N);
+  SGG_LAUNCH_CHECK("sgg_layernorm_hwc_elu_bwd_sums");
+  return SGG_OK;
+}
+
 struct sgg_ln_finalize_desc {      // mirrors include/sgg_hip.h
   const void* workspace;
   const float* gamma;

@@ -53,6 +53,8 @@ SIGNATURES = {
     "sgg_gemm_skinny_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "sgg_gemm_skinny_dgrad": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "sgg_gemm_skinny_wgrad": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "sgg_layernorm_hwc_elu_bwd_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sgg_conv2d_nhwc_wgrad_c3_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_attn_ctx_gemm_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_attn_ctx_gemm_dgrad": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "sgg_attn_ctx_gemm_wgrad": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
@@ -172,6 +174,10 @@ DEFAULT_OPTIONS = {
     # another box 44.02 / 44.07 against 44.32 / 44.18; 30, 26, 24, 20: equal to none (profiles/r05_early_forward_cu_cap_ab*.log).
     # Tiles, products and summation orders are unchanged: bit-identical results (tests/test_concurrency_gpu.py)
     "g_early_cus": 28,
+    # True: the LayerNorm backward of conv1_1's output runs without its apply pass - conv1_1's filter gradient, the only consumer of
+    # that dy, computes it itself (sgg_conv2d_nhwc_wgrad_c3_ln): one read of y and da instead of the apply pass (2 reads + 1 write of
+    # 411 MB at batch 64) + the filter gradient's read of dy, on the tail of every encoder backward
+    "c3_ln_bwd_fused": True,
     "d_side_cus": 0,      # the same for D's encoder forward on the side stream (beside G's forward and G's head)
     "fwd_cus": 0,         # the same for every encoder forward (16: G's and D's forwards of an update on disjoint halves of the chip)
     # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward /
@@ -529,6 +535,30 @@ class HipKernels:
         resident kernels (halo incl. conv1_3 through the space-to-depth view, band-resident 5x5 stride 2)."""
         return (self.conv_halo and self.conv_precision in (2, 3) and cin <= 512 and
                 self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision) in (1, 2, 3, 4))
+
+    def ln_elu_bwd_sums(self, y, da, gamma, beta, stats, means, ws):
+        """The reduction half of ln_elu_bwd (partial sums into the layer's own workspace `ws` for ln_bwd_finalize) + the two per-sample
+        means [B,2] of the backward, WITHOUT the apply pass: the consumer computes dy itself (conv_c3_wgrad_ln)."""
+        self._dev(y, da, gamma, beta, stats, means, ws)
+        B, H, W, C = y.shape
+        nb = 4.0 * 2 * y.numel()
+        self._check(self._timed("ln_elu_bwd_sums(call)", 0.0, lambda: self.lib.sgg_layernorm_hwc_elu_bwd_sums(
+            _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(means), None, None, None, B, H * W, C, _p(ws), ws.numel(), self._stream()), nb),
+            "sgg_layernorm_hwc_elu_bwd_sums")
+
+    def conv_c3_wgrad_ln(self, x, y, da, gamma, beta, stats, means, dw):
+        """conv1_1's filter gradient with dy = LayerNormBackward(y, da) computed inside the kernel (include/sgg_hip.h)."""
+        self._dev(x, y, da, gamma, beta, stats, means, dw)
+        B, H, W, _ = x.shape
+        assert tuple(y.shape) == (B, H, W, 32) and tuple(da.shape) == (B, H, W, 32) and tuple(dw.shape) == (3, 3, 3, 32)
+        assert x.is_contiguous() and y.is_contiguous() and da.is_contiguous() and dw.is_contiguous()
+        need = self.lib.sgg_conv2d_nhwc_wgrad_workspace_bytes(B, H, W, 3, H, W, 32, 3, 3)
+        ws = self.workspace(need)
+        flops = 2.0 * B * H * W * 32 * 27
+        nb = 4.0 * (x.numel() + y.numel() + da.numel())
+        self._check(self._timed("conv_c3_wgrad_ln(call: LN-backward apply fused + slab reduce)", flops, lambda: self.lib.sgg_conv2d_nhwc_wgrad_c3_ln(
+            _p(x), _p(y), _p(da), _p(gamma), _p(beta), _p(stats), _p(means), _p(dw), B, H, W, 1, 1, _p(ws), ws.numel(), self._stream()), nb),
+            "sgg_conv2d_nhwc_wgrad_c3_ln")
 
     def ln_workspace_bytes(self, shape):
         B, H, W, C = shape

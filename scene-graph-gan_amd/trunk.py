@@ -420,11 +420,16 @@ class Trunk:
                 K.presplit16(dy, self._dctx16, self._am(1, n - 1))
                 dy, dy_s16 = self._dctx16, True
         cur = -1                                   # dY buffer holding dy (-1: the caller's dctx)
+        c3_fused = None                            # dA of layer 0 when its LayerNorm backward ran without the apply pass (below)
         for j in range(n - 1, -1, -1):
             lay = self.layers[j]
             prv = self.layers[j - 1] if j else None
 
             def wgrad(dy=dy, j=j, lay=lay, prv=prv, dy_s16=dy_s16):
+                if j == 0 and c3_fused is not None:
+                    # conv1_1: dy was never written - the filter gradient computes it from the LayerNorm backward's operands
+                    K.conv_c3_wgrad_ln(self.images, lay["y"], c3_fused, lay["gamma"], lay["beta"], lay["stats"], self._ln0_means, lay["gw"])
+                    return
                 if prv is not None and prv.get("fused_now"):
                     # the input activation was never written: the wgrad kernel applies LayerNorm + ELU to the producing layer's y
                     K.conv_wgrad(prv["y"], dy, lay["gw"], lay["s"], self._am(0, j - 1), self._am(1, j), ln=(prv["stats"], prv["gamma"], prv["beta"]),
@@ -479,6 +484,17 @@ class Trunk:
                 side.wait_event(ev)
                 wgrad_on_side()
             nxt_s16 = bool(prev.get("dy_s16")) and prev.get("ws_mode") == getattr(K, "conv_precision", 0) and self._ln_fin is not None
+            if (j == 1 and prev["cin"] == 3 and prev["region"] is None and self._ln_fin is not None and hasattr(K, "conv_c3_wgrad_ln")
+                    and getattr(K, "c3_ln_bwd_fused", False) and prev["out_shape"][3] == 32):
+                # conv1_1's LayerNorm: the reductions only.  Its dy has ONE consumer, conv1_1's filter gradient, which computes it
+                # from (y, dA) itself (sgg_conv2d_nhwc_wgrad_c3_ln): no apply pass, no dy tensor.  dA stays untouched until then
+                # (the loop ends with that filter gradient; the next backward on this encoder is ordered behind it).
+                if getattr(self, "_ln0_means", None) is None:
+                    self._ln0_means = torch.empty((B, 2), device=dA.device, dtype=dA.dtype)
+                K.ln_elu_bwd_sums(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], self._ln0_means, prev["ln_ws"])
+                c3_fused = dA
+                dy, cur, dy_s16 = None, nxt, False
+                continue
             if nxt_s16:
                 K.ln_elu_bwd(prev["y"], dA, prev["gamma"], prev["beta"], prev["stats"], dYp, None, None, None, self._am(1, j - 1),
                              region=prev["region"], ws=prev["ln_ws"], out_s16=True, pq=self.pq[j - 1])

@@ -5,7 +5,7 @@
 #   pmc     : two separate --pmc passes (FETCH_SIZE / WRITE_SIZE) for the roofline `traffic` field
 set -e
 STEP=${1:-tests}
-TAG=${2:-r04}
+TAG=${2:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -917,3 +917,58 @@ def test_layernorm_bwd_deferred_finalize_equals_immediate(hip):
     for lay, (dg1, db1, dbias1) in zip(lays, refs):
         assert torch.equal(lay["dgamma"], dg1) and torch.equal(lay["dbeta"], db1)
         assert lay["dbias"] is None or torch.equal(lay["dbias"], dbias1)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32), (3, 13, 45), (1, 8, 64), (4, 64, 64)])
+def test_conv1_1_filter_gradient_fused_with_layernorm_backward(hip, ref, shape):
+    """sgg_layernorm_hwc_elu_bwd_sums + sgg_conv2d_nhwc_wgrad_c3_ln: conv1_1's filter gradient with dy = LayerNormBackward(y, da)
+    computed inside the kernel (generator_with_attention.py:29-30 under optimizer.minimize) against fp64 autograd through
+    ELU(LN(y)) -> Conv2DBackpropFilter, against the unfused HIP path (apply pass, then the plain conv1_1 filter gradient: same f32
+    arithmetic up to the contraction of the compiler), and the deferred parameter-gradient reductions bit for bit (the partial sums in
+    the workspace are those of sgg_layernorm_hwc_elu_bwd).  Ragged tiles at the right / bottom edge included."""
+    B, H, W = shape
+    x, y, da = rnd((B, H, W, 3), 1), rnd((B, H, W, 32), 2, 1.7) + 0.3, rnd((B, H, W, 32), 3)
+    gamma, beta = 1.0 + rnd((32,), 4, 0.2), rnd((32,), 5, 0.2)
+    # fp64 reference
+    dy_ref, dg_ref, db_ref = torch.empty((B, H, W, 32), dtype=torch.float64), torch.empty(32, dtype=torch.float64), torch.empty(32, dtype=torch.float64)
+    st64 = torch.empty((B, 2), dtype=torch.float64)
+    a64 = torch.empty((B, H, W, 32), dtype=torch.float64)
+    ref.ln_elu_fwd(y.double(), gamma.double(), beta.double(), a64, st64)
+    ref.ln_elu_bwd(y.double(), da.double(), gamma.double(), beta.double(), st64, dy_ref, dg_ref, db_ref, None)
+    dw_ref = torch.empty((3, 3, 3, 32), dtype=torch.float64)
+    ref.conv_wgrad(x.double(), dy_ref, dw_ref, 1)
+    # HIP: forward statistics, then the fused backward
+    xd, yd, dad, gd, bd = dev(x), dev(y), dev(da), dev(gamma), dev(beta)
+    a, st = torch.empty((B, H, W, 32), device="cuda"), torch.empty((B, 2), device="cuda")
+    hip.ln_elu_fwd(yd, gd, bd, a, st)
+    ws = torch.zeros(hip.ln_workspace_bytes((B, H, W, 32)), dtype=torch.uint8, device="cuda")      # (zeroed: compared as a whole below)
+    means = torch.full((B, 2), float("nan"), device="cuda")
+    hip.ln_elu_bwd_sums(yd, dad, gd, bd, st, means, ws)
+    dw = torch.full((3, 3, 3, 32), float("nan"), device="cuda")
+    hip.conv_c3_wgrad_ln(xd, yd, dad, gd, bd, st, means, dw)
+    close(dw, dw_ref, rtol=5e-6, what="fused conv1_1 filter gradient vs fp64")
+    # the unfused path on the same operands
+    ws2 = torch.zeros_like(ws)
+    dy = torch.empty((B, H, W, 32), device="cuda")
+    hip.ln_elu_bwd(yd, dad, gd, bd, st, dy, None, None, None, ws=ws2)
+    dw2 = torch.empty((3, 3, 3, 32), device="cuda")
+    old = hip.conv_precision
+    hip.conv_precision = 0
+    try:
+        hip.conv_wgrad(xd, dy, dw2, 1)
+    finally:
+        hip.conv_precision = old
+    close(dw, dw2, rtol=2e-6, what="fused vs unfused conv1_1 filter gradient")
+    assert torch.equal(ws, ws2), "the partial sums of the reductions-only entry point differ from sgg_layernorm_hwc_elu_bwd's"
+    # twice the same launch: bit-identical (fixed summation order)
+    dw3 = torch.empty_like(dw)
+    hip.conv_c3_wgrad_ln(xd, yd, dad, gd, bd, st, means, dw3)
+    assert torch.equal(dw, dw3)
+    # the per-sample means are what the apply pass derives: dy recomputed on the host from them equals the apply pass's dy
+    m = means.cpu().double()
+    s = st.cpu().double()
+    xh = (y.double() - s[:, 0].view(B, 1, 1, 1)) * s[:, 1].view(B, 1, 1, 1)
+    n = xh * gamma.double() + beta.double()
+    dn = da.double() * torch.where(n > 0, torch.ones_like(n), torch.exp(n))
+    dy_host = s[:, 1].view(B, 1, 1, 1) * (dn * gamma.double() - m[:, 0].view(B, 1, 1, 1) - xh * m[:, 1].view(B, 1, 1, 1))
+    close(dy, dy_host, rtol=5e-6, what="dy from the published means vs the apply pass")
