@@ -443,9 +443,13 @@ class Trunk:
                         K.conv_wgrad(x_in, dy, lay["gw"], lay["s"], self._am(0, j - 1) if j else None, self._am(1, j))
                     else:
                         K.conv_wgrad(x_in, dy, lay["gw"], lay["s"])
-            def wgrad_on_side(cur=cur):
+            def wgrad_on_side(cur=cur, lay=lay):
                 with torch.cuda.stream(side):
                     wgrad()
+                    if not lay["has_ln"]:
+                        # last conv: BiasAddGrad = column sums of dy - read only by the optimiser, so it leaves the chain with the
+                        # filter gradient (the head's f32 gradient: a tensor of the caller that nothing overwrites before the join)
+                        K.colsum(dy_f32.view(-1, lay["cout"]), lay["gb"], False)
                     if cur >= 0:
                         reader_done[cur] = torch.cuda.Event()
                         reader_done[cur].record(side)
@@ -455,7 +459,7 @@ class Trunk:
             elif not late:
                 side.wait_stream(main)            # dy_j (and its amax word) are complete
                 wgrad_on_side()
-            if not lay["has_ln"]:
+            if not lay["has_ln"] and side is None:
                 # last conv: BiasAddGrad = column sums of dy (LN layers get theirs from ln_elu_bwd below)
                 K.colsum(dy_f32.view(-1, lay["cout"]), lay["gb"], False)
             if j == 0:
