@@ -87,6 +87,12 @@ int sgg_conv_prepare_weights(const sgg_conv_weight_desc* layers, int n_layers, i
 /* The library reads no environment variables and keeps no mutable global state: every kernel choice is a function of the
  * arguments (w_split_layout here, `algo` of sgg_conv2d_nhwc_wgrad). */
 int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);
+/* The same question for a launch whose source operand (x of the forward, dy of the dgrad) WILL arrive pre-split (operand_format 1):
+ * 3x3 stride-1 layers with Cout % 64 == 0 (not 128) and Cin % 64 == 0 in precision 2 then also run on the producer / consumer kernel,
+ * in its four-block form (4 blocks x 64 columns per workgroup; the patch by LDS-DMA only): 4 is returned for them as well, and such a
+ * launch MUST pass operand_format 1 (an f32 source with this layout is refused).  generator_with_attention.py:41,44: the
+ * Conv2DBackpropInput of conv2_2 and conv2_3. */
+int sgg_conv_wsplit_layout_presplit(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision);
 int sgg_conv_split_weights_frag(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
 int sgg_conv_split_weights_frag16(const float* in, void* out, int taps, int N, int C, int precision, const float* amax, void* stream);
 int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w_split, const float* bias, float* y, int B, int Hi, int Wi, int Cin,

@@ -919,8 +919,10 @@ extern "C" int sgg_conv2d_nhwc_fwd(const float* x, const float* w, const void* w
   if (w_split_layout == 1 || w_split_layout == 4) {        // halo-resident 3x3 stride-1 kernels, weights in MFMA fragment order
     SGG_CHECK_ARG(w_split && sgg_halo_applicable(KH, KW, stride, Hi, Wi, Cin, Cout, precision) && pad_t == 1 && pad_l == 1,
                   "sgg_conv2d_nhwc_fwd: w_split_layout 1 / 4 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
-    SGG_CHECK_ARG(w_split_layout != 4 || sgg_halo_pc_applicable(Cin, Cout, precision),
-                  "sgg_conv2d_nhwc_fwd: w_split_layout 4 needs Cout %% 128 == 0, Cin %% 64 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
+    SGG_CHECK_ARG(w_split_layout != 4 || sgg_halo_pc_applicable(Cin, Cout, precision) ||
+                      (sgg_halo_pc64_applicable(Cin, Cout, precision) && (operand_format & 1) && !ln_stats),
+                  "sgg_conv2d_nhwc_fwd: w_split_layout 4 needs Cout %% 128 == 0, Cin %% 64 == 0, precision 2 or 3 (sgg_conv_wsplit_layout) - or "
+                  "Cout %% 64 == 0 with a pre-split x in precision 2 (sgg_conv_wsplit_layout_presplit)");
     HaloParams h;
     h.src = x; h.wfrag = w_split; h.bias = bias; h.out = y; h.amax_src = amax_x; h.amax_w = amax_w; h.tile_stats = tile_stats;
     h.ln_stats = ln_stats; h.ln_gamma = ln_gamma; h.ln_beta = ln_beta;
@@ -1014,7 +1016,8 @@ extern "C" int sgg_conv2d_nhwc_dgrad(const float* dy, const float* w, const void
     SGG_CHECK_ARG(w_split && sgg_halo_applicable(KH, KW, stride, Hi, Wi, Cout, Cin, precision) && pad_t == 1 && pad_l == 1 &&
                       Ho == Hi && Wo == Wi,
                   "sgg_conv2d_nhwc_dgrad: w_split_layout 1 / 4 needs 3x3 stride 1, H %% 8 == W %% 8 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
-    SGG_CHECK_ARG(w_split_layout != 4 || sgg_halo_pc_applicable(Cout, Cin, precision),
+    SGG_CHECK_ARG(w_split_layout != 4 || sgg_halo_pc_applicable(Cout, Cin, precision) ||
+                      (sgg_halo_pc64_applicable(Cout, Cin, precision) && (operand_format & 1)),
                   "sgg_conv2d_nhwc_dgrad: w_split_layout 4 needs Cin %% 128 == 0, Cout %% 64 == 0, precision 2 or 3 (sgg_conv_wsplit_layout)");
     SGG_CHECK_ARG((size_t)B * Ho * Wo * Cout * sizeof(float) < 0x80000000ull, "sgg_conv2d_nhwc_dgrad: dy exceeds 2 GiB");
     HaloParams h;

@@ -53,6 +53,8 @@ void sgg_halo_launch(const HaloParams& p, int precision, hipStream_t st);
 // producer / consumer form for 128-column tiles in the two-piece modes (conv_halo_pc.hip; weights in w_split_layout 4);
 // sgg_halo_launch dispatches to it when HaloParams::frag16 is set
 int sgg_halo_pc_applicable(int C, int N, int precision);
+// its four-block form for 64-column tiles (pre-split sources only)
+int sgg_halo_pc64_applicable(int C, int N, int precision);
 void sgg_halo_pc_launch(const HaloParams& p, int precision, hipStream_t st);
 
 // ---- halo-resident 3x3 stride-1 wgrad (conv_wgrad_halo.hip) ---------------------------------------------------

@@ -688,6 +688,14 @@ extern "C" int sgg_conv_wsplit_layout(int KH, int KW, int stride, int H, int W, 
   return 0;
 }
 
+// The same question for a launch whose SOURCE operand (x of the forward, dy of the dgrad) will arrive PRE-SPLIT (operand_format 1):
+// the layers with 64 output columns (Cout % 64 == 0, not 128; Cin % 64 == 0; precision 2) then also run on the producer / consumer
+// kernel - its four-block form, which stages the patch by LDS-DMA only (conv_halo_pc.hip) -, so 4 is returned for them as well.
+extern "C" int sgg_conv_wsplit_layout_presplit(int KH, int KW, int stride, int H, int W, int Cin, int Cout, int precision) {
+  if (sgg_halo_applicable(KH, KW, stride, H, W, Cin, Cout, precision) && sgg_halo_pc64_applicable(Cin, Cout, precision)) return 4;
+  return sgg_conv_wsplit_layout(KH, KW, stride, H, W, Cin, Cout, precision);
+}
+
 // f32 [taps][N][C] -> two 16-bit planes in the B-fragment order of v_mfma_f32_16x16x32: [tap][C/32][N/16][plane][lane] x 16 B,
 // lane l of fragment (tap, chunk, n-tile, plane) holds w[tap][n-tile*16 + (l&15)][chunk*32 + 8*(l>>4) .. +8]  (w_split_layout 4)
 template <bool HALF>

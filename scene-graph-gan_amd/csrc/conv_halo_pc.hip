@@ -25,17 +25,21 @@
 
 #define PC_PITCH 12
 #define PC_BLKB (10 * PC_PITCH * 64)      // bytes of one plane of one block's patch
-#define PC_NB 2
-#define PC_PLANEB (PC_NB * PC_BLKB)
 #define PC_P 2
-#define PC_PATCHB (PC_P * PC_PLANEB)      // one patch buffer
-#define PC_SLOTB 16384                    // one tap of weight fragments for 128 columns: [n-tile 4][k-step 2][plane 2][lane 64] x 16 B
 #define PC_D 4                            // ring slots: the DMA of tap g + 4 is issued behind barrier g and must have landed by barrier g + 3
-#define PC_ITEMS (PC_NB * 400)
 #ifndef PC_INTERLEAVE
 #define PC_INTERLEAVE 1
 #endif
-#define PC_NPASS 4                        // 800 (block, patch pixel, 8-channel group) items over the 256 producer threads
+// 1 (round 5): with the patch DMA (DMAP) the four producer waves split by ROLE - waves 4, 5 move the weight fragments of every tap,
+// waves 6, 7 the patch (one plane each), a few DMAs per tap over taps 0 .. 7 of the chunk before, waited for ONCE in front of that
+// chunk's last barrier.  vmcnt retires in order: with all four waves doing both, the first wait for a weight fragment behind a
+// patch DMA (tap 3) was a wait for the whole patch, i.e. the patch had three taps (~1.2 us) to arrive - a burst of 30 / 60 KB per CU
+// that every CU issues at the same tap; split, it has eight taps and is issued evenly.  0: every producer wave does both (round 4).
+#ifndef PC_SPLIT_PRODUCERS
+#define PC_SPLIT_PRODUCERS 1
+#endif
+// s_waitcnt immediate of gfx9 for vmcnt(n) alone (expcnt, lgkmcnt: no wait): vmcnt low 4 bits in [3:0], its high 2 bits in [15:14]
+constexpr int pc_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
 // XOR swizzle of the 16-byte chunk index inside a pixel's 64-byte row (write and read side).  With the 16x16x32 operand read (16
 // lanes = two patch rows x 8 pixels take one chunk each, four such groups per ds_read_b128) every read of every tap is conflict free
@@ -47,9 +51,26 @@ typedef __attribute__((address_space(3))) void* pc_lds_ptr;
 
 // DMAP: the source is a PRE-SPLIT tensor (split16.h; HALF, no LN prologue): the producers stage the patch by LDS-DMA as well - no
 // staging registers, no vector arithmetic at all on the SIMDs the MFMA waves run on.
-template <bool HALF, bool LNP, bool DMAP = false>
+// NB (round 5): 8x8 blocks of a workgroup tile.  2: 2 blocks x 128 output columns (a consumer wave = one block x one 64-column half);
+// 4: FOUR blocks x 64 columns for the 64-column launches (conv2_2's and conv2_3's dgrad: a consumer wave = one block x all 64
+// columns - the same 64 pixels x 64 columns per wave, the same operand reads and MFMAs per tap; the ring slot of a tap is 8 KiB, the
+// patch of a chunk 60 KiB: 153 of the 160 KiB of LDS).  With the patch DMA only.
+template <bool HALF, bool LNP, bool DMAP = false, int NB = 2>
 __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
   static_assert(!DMAP || (HALF && !LNP), "patch DMA: pre-split fp16 pieces, no prologue");
+  static_assert(NB == 2 || (NB == 4 && DMAP), "four-block tiles: pre-split sources only");
+  constexpr int PC_NB = NB;
+  constexpr int BN = 256 / NB;                          // output columns of a workgroup tile
+  constexpr int PC_PLANEB = PC_NB * PC_BLKB;
+  constexpr int PC_PATCHB = PC_P * PC_PLANEB;           // one patch buffer
+  constexpr int PC_SLOTB = (BN / 16) * 2048;            // one tap of weight fragments for BN columns: [n-tile BN / 16][plane 2][lane 64] x 16 B
+  constexpr int PC_ITEMS = PC_NB * 400;
+  constexpr int PC_NPASS = (PC_ITEMS + 255) / 256;      // (block, patch pixel, 8-channel group) items over the 256 producer threads
+  constexpr int WQ = PC_SLOTB / 4096;                   // weight DMAs per producer wave and tap (1 KiB each)
+  constexpr int DPP = PC_NB * 120 / 16;                 // patch DMAs per plane and chunk (16 slots of 64 B each): 15 / 30
+  constexpr int DPW = (DPP + 1) / 2;                    // ... of which a producer wave issues up to 8 / 15
+  constexpr int PQ = NB == 2 ? 8 : 16;                  // patch DMAs in a producer wave's queue per chunk (the rest: fillers)
+  constexpr int PLQ = DMAP ? PQ : 2 * PC_NPASS;         // patch loads / DMAs per chunk in the vmcnt queue of a producer wave
   // ONE __shared__ object: with the LayerNorm parameters in an array of their own the compiler waits vmcnt(0) - for every weight DMA
   // in flight - in front of each patch write (cdna_hip_programming.md, "a second __shared__ object beside the glds staging array")
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PC_PATCHB + PC_D * PC_SLOTB + (LNP ? 4096 : 0) + (DMAP ? 1024 : 0)];
@@ -57,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
   float* const lnp_s = reinterpret_cast<float*>(lds + 2 * PC_PATCHB + PC_D * PC_SLOTB);      // gamma[0..511], beta at +512 (C <= 512: host check)
 
   // ---- persistent workgroup: as conv_halo3_kernel (XCD k owns a contiguous eighth of the M-tiles, its workgroups walk it interleaved)
-  const int ntiles_n = p.N / 128;
+  const int ntiles_n = p.N / BN;
   const int mtiles = (p.nblk + PC_NB - 1) / PC_NB;
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int nt = jx % ntiles_n;
@@ -65,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
   const int mt_begin = (int)(((long long)xcd * mtiles) >> 3) + jx / ntiles_n;
   const int mt_end = (int)(((long long)(xcd + 1) * mtiles) >> 3);
   if (mt_begin >= mt_end) return;             // (whole workgroup: no barrier is ever executed by anyone)
-  const int n0 = nt * 128;
+  const int n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nch = p.C >> 5;
@@ -88,6 +109,132 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     const int pt = tid - 256, pw = wave - 4;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wfrag), 0, p.w_bytes, 0x00020000);
+    if constexpr (DMAP && PC_SPLIT_PRODUCERS) {
+      const unsigned w_slab2 = (unsigned)(p.N >> 5) * 4096u;
+      if (pw < 2) {
+        // ---- weight waves: half of every tap's slot each (W2 DMAs of 1 KiB per tap); in their queue nothing but these ----------------
+        constexpr int W2 = PC_SLOTB / 2048;
+        const unsigned w_lane2 = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * (unsigned)(PC_SLOTB / 2) + (unsigned)lane * 16u;
+        int d_cc = 0, d_tap = 0, d_slot = 0;
+        auto issue = [&]() __attribute__((always_inline)) {
+          const unsigned base = (unsigned)(d_tap * nch + d_cc) * w_slab2 + w_lane2;
+          unsigned char* dst = ring + d_slot * PC_SLOTB + pw * (PC_SLOTB / 2);
+#pragma unroll
+          for (int q = 0; q < W2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (pc_lds_ptr)(dst + q * 1024), 16, base + (unsigned)(q * 1024), 0, 0, 0);
+          if (++d_tap == 9) {
+            d_tap = 0;
+            if (++d_cc == nch) d_cc = 0;
+          }
+          d_slot = (d_slot + 1) & (PC_D - 1);
+        };
+#pragma unroll
+        for (int k = 0; k < PC_D; ++k) issue();
+        __builtin_amdgcn_s_waitcnt(pc_vmcnt(0));
+        __builtin_amdgcn_s_barrier();             // barrier "-1": the fragments of taps 0 .. 3 are in LDS
+        for (int tile = mt_begin; tile < mt_end; tile += tstride)
+          for (int cc = 0; cc < nch; ++cc) {
+#pragma unroll
+            for (int T = 0; T < 9; ++T) {
+              // the fragments of tap g + 1 (issued behind barrier g - 3) must have landed; younger: those of taps g + 2, g + 3
+              __builtin_amdgcn_s_waitcnt(pc_vmcnt(2 * W2));
+              __builtin_amdgcn_s_barrier();       // barrier g
+              issue();                            // tap g + 4 into slot g % 4 (the consumers have finished reading tap g)
+            }
+          }
+        __builtin_amdgcn_s_waitcnt(pc_vmcnt(0));  // (the last DMAs target this workgroup's LDS: they must not outlive it)
+        return;
+      }
+      // ---- patch waves: plane pl of every chunk, DPP instructions of 16 slots, PT per tap over taps 0 .. 7 of the chunk before -------
+      const int pl = pw - 2;
+      constexpr int PT = (DPP + 7) / 8;
+      unsigned pm_rel[DPP];
+      int pm_meta[DPP];            // bits 0..3 border bits, 4..5 block, 6 valid
+#pragma unroll
+      for (int k = 0; k < DPP; ++k) {
+        const int slot = 16 * k + (lane >> 2);      // slot inside the plane: [block][row 0..9][pitch 12]
+        const int blk = slot / 120, r = slot - 120 * blk;
+        const int ry = r / PC_PITCH, rx = r - ry * PC_PITCH;
+        const int piece = (lane & 3) ^ pc_sw(ry, rx);
+        pm_rel[k] = (unsigned)((ry * p.in_rs + rx * p.in_ps) * 4 + piece * 16);
+        pm_meta[k] = ((ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3)) | (blk << 4) | ((int)(rx < 10) << 6);
+      }
+      int s_grow[PC_NB], s_by[PC_NB], s_bx[PC_NB];
+#pragma unroll
+      for (int j = 0; j < PC_NB; ++j) {
+        const int beta = mt_begin * PC_NB + j;
+        s_grow[j] = beta / p.bw;
+        s_bx[j] = beta % p.bw;
+        s_by[j] = s_grow[j] % p.bh;
+      }
+      int s_tile = mt_begin, s_cc = 0;
+      unsigned base[PC_NB];
+      int bbits[PC_NB];
+      // block origins and border bits of the next (tile, chunk) of the stream -> base / bbits; past the last tile: out of range (zeros)
+      auto next_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PC_NB; ++j) {
+          const bool dead = (s_tile >= mt_end) | (s_tile * PC_NB + j >= p.nblk);
+          base[j] = (unsigned)(((s_grow[j] * 8 - 1) * p.in_rs + (s_bx[j] * 8 - 1) * p.in_ps + (s_cc >> 1) * p.in_cA + (s_cc & 1) * p.in_cB) * 4);
+          bbits[j] = dead ? 15 : ((s_by[j] == 0) | ((s_by[j] == p.bh - 1) << 1) | ((s_bx[j] == 0) << 2) | ((s_bx[j] == p.bw - 1) << 3));
+          if (dead) base[j] = SGG_OOB;
+        }
+        if (++s_cc == nch) {        // advance to this workgroup's next tile
+          s_cc = 0;
+          s_tile += tstride;
+#pragma unroll
+          for (int j = 0; j < PC_NB; ++j) {
+            s_bx[j] += adv_cols;
+            s_grow[j] += adv_rows;
+            s_by[j] += adv_rows;
+            if (s_bx[j] >= p.bw) {
+              s_bx[j] -= p.bw;
+              ++s_grow[j];
+              ++s_by[j];
+            }
+            while (s_by[j] >= p.bh) s_by[j] -= p.bh;
+          }
+        }
+      };
+      // instructions [k0, k0 + n) of the plane into patch buffer dstbuf
+      auto patch_part = [&](unsigned char* dstbuf, auto k0_c, auto n_c) __attribute__((always_inline)) {
+        constexpr int k0 = decltype(k0_c)::value, n = decltype(n_c)::value;
+#pragma unroll
+        for (int k = k0; k < k0 + n && k < DPP; ++k) {
+          const int blk = (pm_meta[k] >> 4) & 3;
+          unsigned b0 = base[0];
+          int bb = bbits[0];
+#pragma unroll
+          for (int j = 1; j < PC_NB; ++j) {
+            b0 = blk == j ? base[j] : b0;
+            bb = blk == j ? bbits[j] : bb;
+          }
+          const bool bad = !((pm_meta[k] >> 6) & 1) | (((pm_meta[k] & 15) & bb) != 0) | (b0 == SGG_OOB);
+          const unsigned off = bad ? SGG_OOB : b0 + pm_rel[k];
+          // (the plane's byte offset as SCALAR offset: the immediate offset field would move the LDS address too, scripts/ubench/dma_oob.hip)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (pc_lds_ptr)(dstbuf + pl * PC_PLANEB + k * 1024), 16, off, pl * 64, 0, 0);
+        }
+      };
+      next_chunk();
+      patch_part(lds, std::integral_constant<int, 0>{}, std::integral_constant<int, DPP>{});      // chunk 0, whole
+      __builtin_amdgcn_s_waitcnt(pc_vmcnt(0));
+      __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 is in LDS
+      int cur = 0;
+      for (int tile = mt_begin; tile < mt_end; tile += tstride)
+        for (int cc = 0; cc < nch; ++cc) {
+          unsigned char* nb = lds + (cur ^ 1) * PC_PATCHB;      // the buffer the consumers left at the last barrier
+          next_chunk();
+#define PC_PTAP(T)                                                                                            \
+          patch_part(nb, std::integral_constant<int, (T) * PT>{}, std::integral_constant<int, PT>{});          \
+          __builtin_amdgcn_s_barrier();
+          PC_PTAP(0) PC_PTAP(1) PC_PTAP(2) PC_PTAP(3) PC_PTAP(4) PC_PTAP(5) PC_PTAP(6) PC_PTAP(7)
+#undef PC_PTAP
+          __builtin_amdgcn_s_waitcnt(pc_vmcnt(0));            // the next patch has landed ...
+          __builtin_amdgcn_s_barrier();                        // ... behind barrier 8
+          cur ^= 1;
+        }
+      return;
+    }
     const float sa = ldexpf(1.f, ea);
     if constexpr (LNP) {
       for (int c = pt; c < p.ln_nc; c += 256) {
@@ -101,11 +248,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
 #pragma unroll
     for (int j = 0; j < PC_NPASS; ++j) {
       const int it = pt + 256 * j;
-      const int blk = (it / 400) & 1, r = it % 400;
+      const int blk = (it / 400) % PC_NB, r = it % 400;
       const int px = r >> 2, ch8 = r & 3;
       const int ry = px / 10, rx = px % 10;
       it_rel[j] = (unsigned)((ry * p.in_rs + rx * p.in_ps + ch8 * 8) * 4);
       const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
+      // (the register-staged patch - one block bit in it_meta - serves two-block tiles only: NB == 4 implies DMAP, static_assert above)
       it_meta[j] = (blk * PC_BLKB + (ry * PC_PITCH + rx) * 64 + ((ch8 ^ pc_sw(ry, rx)) << 4)) | (bits << 20) | (blk << 24) |
                    (ch8 << 26) | ((it < PC_ITEMS) << 28);
     }
@@ -193,12 +341,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         for (int pp = 0; pp < PC_P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PC_PLANEB + (it_meta[j] & 0xfffff)) = pl[pp];
       }
     };
-    // ---- DMAP: the patch of one chunk = 2 planes x 240 slots (two blocks of 10 rows x pitch 12) x 64 B = 30 DMA instructions of 16
-    // slots; wave pw issues instructions 8 pw .. 8 pw + 7 of the sequence [plane][15 + 1 filler] (the filler goes to a scratch KiB
-    // with out-of-range offsets: every wave issues exactly eight, so one vmcnt protocol serves all four).  Lane l of an instruction
-    // writes LDS position l & 3 of slot 16 q + (l >> 2), so it FETCHES the piece the swizzle puts there: (l & 3) ^ pc_sw(ry, rx).
-    unsigned dm_rel[8];
-    int dm_meta[8];             // bits 0..3 border bits, 4 block, 5 valid
+    // ---- DMAP: the patch of one chunk = 2 planes x (NB * 120) slots (NB blocks of 10 rows x pitch 12) x 64 B = 2 x DPP DMA instructions of
+    // 16 slots; the two producer waves of a plane issue instructions [DPW h, DPW h + DPW) of it (h = pw & 1), padded with fillers to PQ
+    // per wave (a filler goes to a scratch KiB with out-of-range offsets: every wave issues exactly PQ, so one vmcnt protocol serves all
+    // four).  Lane l of an instruction writes LDS position l & 3 of slot 16 q + (l >> 2), so it FETCHES the piece the swizzle puts
+    // there: (l & 3) ^ pc_sw(ry, rx).
+    unsigned dm_rel[PQ];
+    int dm_meta[PQ];             // bits 0..3 border bits, 4..5 block, 6 valid
     auto patch_dma = [&](unsigned char* dstbuf) __attribute__((always_inline)) {
       unsigned base[PC_NB];
       int bbits[PC_NB];
@@ -209,17 +358,23 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
         bbits[j] = dead ? 15 : ((s_by[j] == 0) | ((s_by[j] == p.bh - 1) << 1) | ((s_bx[j] == 0) << 2) | ((s_bx[j] == p.bw - 1) << 3));
         if (dead) base[j] = SGG_OOB;
       }
-      const int plane = pw >> 1;
-      unsigned char* dst = dstbuf + plane * PC_PLANEB + (pw & 1) * 8 * 1024;
+      const int plane = pw >> 1, hh = pw & 1;
+      unsigned char* dst = dstbuf + plane * PC_PLANEB + hh * DPW * 1024;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int blk = (dm_meta[k] >> 4) & 1;
-        const unsigned b0 = blk ? base[1] : base[0];
-        const int bb = blk ? bbits[1] : bbits[0];
-        const bool bad = !((dm_meta[k] >> 5) & 1) | (((dm_meta[k] & 15) & bb) != 0) | (b0 == SGG_OOB);
+      for (int k = 0; k < PQ; ++k) {
+        const int blk = (dm_meta[k] >> 4) & 3;
+        unsigned b0 = base[0];
+        int bb = bbits[0];
+#pragma unroll
+        for (int j = 1; j < PC_NB; ++j) {
+          b0 = blk == j ? base[j] : b0;
+          bb = blk == j ? bbits[j] : bb;
+        }
+        const bool bad = !((dm_meta[k] >> 6) & 1) | (((dm_meta[k] & 15) & bb) != 0) | (b0 == SGG_OOB);
         const unsigned off = bad ? SGG_OOB : b0 + dm_rel[k];
-        // (the 16th instruction of a plane does not exist: the waves with pw & 1 send their last one, all lanes invalid, to the scratch)
-        unsigned char* d = ((pw & 1) && k == 7) ? lds + sizeof(lds) - 1024 : dst + k * 1024;
+        // (instructions past the plane's last one, and past this wave's share, do not exist: all lanes invalid, sent to the scratch)
+        const bool real = k < DPW && hh * DPW + k < DPP;
+        unsigned char* d = real ? dst + k * 1024 : lds + sizeof(lds) - 1024;
         // (the plane's byte offset as SCALAR offset: the immediate offset field would move the LDS address too, scripts/ubench/dma_oob.hip)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (pc_lds_ptr)d, 16, off, plane * 64, 0, 0);
       }
@@ -242,25 +397,25 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     };
     if constexpr (DMAP) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int slot = 16 * (8 * (pw & 1) + k) + (lane >> 2);      // slot inside the plane: [block][row 0..9][pitch 12]
-        const int blk = slot >= 120 ? 1 : 0, r = slot - 120 * blk;
+      for (int k = 0; k < PQ; ++k) {
+        const int slot = 16 * (DPW * (pw & 1) + k) + (lane >> 2);      // slot inside the plane: [block][row 0..9][pitch 12]
+        const int blk = slot / 120 < PC_NB ? slot / 120 : PC_NB - 1, r = slot - 120 * blk;
         const int ry = r / PC_PITCH, rx = r - ry * PC_PITCH;
-        const bool valid = slot < 240 && rx < 10;
+        const bool valid = k < DPW && slot < PC_NB * 120 && rx < 10;
         const int piece = (lane & 3) ^ pc_sw(ry, rx);
         dm_rel[k] = (unsigned)((ry * p.in_rs + rx * p.in_ps) * 4 + piece * 16);
-        dm_meta[k] = ((ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3)) | (blk << 4) | ((int)valid << 5);
+        dm_meta[k] = ((ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3)) | (blk << 4) | ((int)valid << 6);
       }
     }
-    // ---- weight fragments: this wave moves pieces 4 pw .. 4 pw + 3 of the tap's sixteen 1-KiB pieces [n-tile 16][plane]
+    // ---- weight fragments: this wave moves a quarter (WQ 1-KiB pieces) of the tap's [n-tile 16][plane] pieces
     const unsigned w_slab = (unsigned)(p.N >> 5) * 4096u;
-    const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * 4096u + (unsigned)lane * 16u;
+    const unsigned w_lane = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * (unsigned)(PC_SLOTB / 4) + (unsigned)lane * 16u;
     int d_cc = 0, d_tap = 0, d_slot = 0;
     auto dma_issue = [&]() __attribute__((always_inline)) {
       const unsigned base = (unsigned)(d_tap * nch + d_cc) * w_slab + w_lane;
-      unsigned char* dst = ring + d_slot * PC_SLOTB + pw * 4096;
+      unsigned char* dst = ring + d_slot * PC_SLOTB + pw * (PC_SLOTB / 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < WQ; ++q)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (pc_lds_ptr)(dst + q * 1024), 16, base + (unsigned)(q * 1024), 0, 0, 0);
       if (++d_tap == 9) {
         d_tap = 0;
@@ -287,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     };
     if constexpr (DMAP) {
       patch_dma(lds);                                        // chunk 0 (chunk c + 1 follows at tap 0 of chunk c, into the other buffer)
-      __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+      __builtin_amdgcn_s_waitcnt(pc_vmcnt(0));               // vmcnt(0)
     } else {
       stage_load(std::integral_constant<int, 0>{});            // chunk 0
       full_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds);
@@ -331,8 +486,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
       // (the BUILTIN, not inline asm: the compiler's own wait insertion must see these waits - with asm it believes every DMA since
       //  the kernel's start is still in flight, its count outgrows the 6-bit counter and it falls back to vmcnt(0) at the chunk loop's
       //  head and in front of the patch writes: a full L2 round trip in the producers once per chunk, the barrier late by as much)
-      if constexpr (T <= 2) __builtin_amdgcn_s_waitcnt(0x4F70);      // vmcnt(16)
-      else __builtin_amdgcn_s_waitcnt(0x0F78);                        // vmcnt(8)
+      // (NB = 2: vmcnt(16) / vmcnt(8); NB = 4: 2 weight DMAs per tap and 16 patch DMAs per chunk: vmcnt(20) / vmcnt(4))
+      if constexpr (T <= 2) __builtin_amdgcn_s_waitcnt(pc_vmcnt(2 * WQ + PLQ));
+      else __builtin_amdgcn_s_waitcnt(pc_vmcnt(2 * WQ));
       if constexpr (T == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next patch is written
       __builtin_amdgcn_s_barrier();             // barrier g
 #ifndef PC_ABL_NODMA
@@ -356,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
   }
 
   // ===================================================================================================================
-  // CONSUMERS (waves 0-3): block wblk = wave >> 1, column half wn0 = (wave & 1) * 64.
+  // CONSUMERS (waves 0-3): NB = 2: block wblk = wave >> 1, column half wn0 = (wave & 1) * 64;  NB = 4: block wblk = wave, all 64 columns.
   // v_mfma_f32_16x16x32_f16 / _bf16: a whole 32-channel chunk per instruction (K = 32), 4 x 4 tiles of 16 pixels x 16 columns per wave,
   // 48 MFMAs of 16 cycles per tap.  Same FLOPs per cycle as the 32x32x16 shape, but the power-limited chip holds a higher clock on
   // it: +6 % measured on this kernel with both shapes issued on the same operands (profiles/r03_halo_pc_mfma_shape.log).
@@ -364,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
   // 8 c4 .. 8 c4 + 7; B operand of tile j: column 16 j + p, the same channels; D: column p, pixels 16 i + 4 c4 + r in register r.
   // ===================================================================================================================
   constexpr int TI = 4, TJ = 4;
-  const int wblk = wave >> 1, wn0 = (wave & 1) * 64;
+  const int wblk = NB == 2 ? wave >> 1 : wave, wn0 = NB == 2 ? (wave & 1) * 64 : 0;
   const int l16 = lane & 15, c4 = lane >> 4;
   const int pyl = l16 >> 3, pxl = l16 & 7;
   f32x4 acc[TI][TJ];
@@ -579,13 +735,23 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
 #ifndef SGG_HALO_PC_DMA
 #define SGG_HALO_PC_DMA 1      // 0: a pre-split source is staged through registers (no arithmetic) like an f32 one
 #endif
+#ifndef SGG_HALO_PC64
+#define SGG_HALO_PC64 1        // 0: no four-block (64-column) tiles
+#endif
 int sgg_halo_pc_applicable(int C, int N, int precision) {
   return SGG_HALO_PC && (precision == 2 || precision == 3) && N % 128 == 0 && C % 64 == 0 && C <= 512;
+}
+// ... and the four-block form (64-column tiles, round 5): N % 64 == 0 but not 128, C % 64 == 0, precision 2, and only with a PRE-SPLIT
+// source (the patch comes by LDS-DMA: there is no register-staged variant of it)
+int sgg_halo_pc64_applicable(int C, int N, int precision) {
+  return SGG_HALO_PC && SGG_HALO_PC64 && SGG_HALO_PC_DMA && precision == 2 && N % 64 == 0 && N % 128 != 0 && C % 64 == 0 && C <= 512;
 }
 
 void sgg_halo_pc_launch(const HaloParams& p_, int precision, hipStream_t st) {
   HaloParams p = p_;
-  const int mtiles = sgg_cdiv(p.nblk, PC_NB), ntn = p.N / 128;
+  const bool four = p.N % 128 != 0;            // (callers checked sgg_halo_pc64_applicable and the pre-split source)
+  const int nb = four ? 4 : 2, bn = 256 / nb;
+  const int mtiles = sgg_cdiv(p.nblk, nb), ntn = p.N / bn;
   int per_xcd = sgg_cdiv(mtiles, 8) * ntn;       // (tile, n-tile) pairs an XCD owns
   const int cus = sgg_persist_cus(p.cu_cap);
   int gx = per_xcd < cus ? per_xcd : cus;          // one workgroup on each of its (32) CUs
@@ -593,6 +759,10 @@ void sgg_halo_pc_launch(const HaloParams& p_, int precision, hipStream_t st) {
   p.gx = gx;
   const dim3 grid((unsigned)(8 * gx)), blk(512);
   const bool half = precision == 2;
+  if (four) {
+    hipLaunchKernelGGL((conv_halo3_pc_kernel<true, false, true, 4>), grid, blk, 0, st, p);
+    return;
+  }
   if (p.src_s16 && half && !p.ln_stats && SGG_HALO_PC_DMA) {      // pre-split source: the patch by LDS-DMA too
     hipLaunchKernelGGL((conv_halo3_pc_kernel<true, false, true>), grid, blk, 0, st, p);
     return;

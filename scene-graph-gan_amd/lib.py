@@ -31,6 +31,7 @@ SIGNATURES = {
     "sgg_conv_split_weights": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
     "sgg_absmax": (_i, [_vp, _ll, _vp, _vp]),
     "sgg_conv_wsplit_layout": (_i, [_i] * 8),
+    "sgg_conv_wsplit_layout_presplit": (_i, [_i] * 8),
     "sgg_conv_s2d_weights": (_i, [_vp, _vp, _i, _i, _vp]),
     "sgg_conv_prepare_weights": (_i, [_vp, _i, _i, _vp]),
     "sgg_conv_split_weights_frag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -149,6 +150,9 @@ DEFAULT_OPTIONS = {
     "conv_halo": True,
     # False: the 128-column 3x3 layers stay on the four-wave halo kernel (w_split_layout 1 instead of 4)
     "halo_pc": True,
+    # True: the dgrads of the 64-column 3x3 layers whose dy arrives pre-split (conv2_2, conv2_3) run on the four-block form of the
+    # producer / consumer kernel (trunk._query_layouts; csrc/conv_halo_pc.hip NB = 4)
+    "halo_pc64": True,
     # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = per layer and per KIND of
     # encoder pass (forward-only / followed by a backward) where trunk.ln_fusion_pays' measured cost model says it pays
     # (trunk._plan_ln_fusion: with pre-split activations 16 of the 44 apply passes of a step at configs[1] run as prologues, 28 as
@@ -340,6 +344,15 @@ class HipKernels:
         lay = self.lib.sgg_conv_wsplit_layout(k, k, stride, H, W, cin, cout, self.conv_precision)
         return 1 if (lay == 4 and not self.halo_pc) else lay
 
+    def conv_wsplit_layout_presplit(self, k, stride, H, W, cin, cout):
+        """conv_wsplit_layout for a launch whose source operand WILL be a pre-split tensor: the 64-column 3x3 layers then also take
+        layout 4 (the four-block form of the producer / consumer kernel; option halo_pc64).  Such a launch must pass x_s16 / dy_s16."""
+        if not self.conv_halo:
+            return 0
+        if not (self.halo_pc and getattr(self, "halo_pc64", True)):
+            return self.conv_wsplit_layout(k, stride, H, W, cin, cout)
+        return self.lib.sgg_conv_wsplit_layout_presplit(k, k, stride, H, W, cin, cout, self.conv_precision)
+
     def split_weights(self, w, out, amax=None, layout=0):
         """w fp32 [kh, kw, N, C] -> out int16 [P, n] sixteen-bit planes (layout 0) or MFMA B fragments (layout 1)."""
         self._dev(w, out, amax)
@@ -390,12 +403,13 @@ class HipKernels:
         return self.lib.sgg_conv2d_nhwc_fwd_tile_stats(y_shape[1], y_shape[2], cin, y_shape[3], k, k, stride, self.conv_precision,
                                                        layout)
 
-    def halo_pc_symbol(self, lnp=False, presplit=False):
+    def halo_pc_symbol(self, lnp=False, presplit=False, n_out=128):
         """Kernel symbol of the producer / consumer 3x3 kernel (csrc/conv_halo_pc.hip; w_split_layout 4); presplit: the source is a
-        pre-split tensor, the patch is staged by LDS-DMA (third template argument)."""
+        pre-split tensor, the patch is staged by LDS-DMA (third template argument); fourth: 8x8 blocks per workgroup tile (2 blocks x
+        128 columns, or 4 x 64 for the 64-column launches)."""
         dma = presplit and not lnp and self.conv_precision == 2
-        return "conv_halo3_pc_kernel<%s,%s,%s>" % ("true" if self.conv_precision == 2 else "false", "true" if lnp else "false",
-                                                   "true" if dma else "false")
+        return "conv_halo3_pc_kernel<%s,%s,%s,%d>" % ("true" if self.conv_precision == 2 else "false", "true" if lnp else "false",
+                                                      "true" if dma else "false", 2 if n_out % 128 == 0 else 4)
 
     def halo_symbol(self, n_out, n_in, lnp=False):
         """Kernel symbol (as rocprofv3 prints it, spaces removed) that csrc/conv_halo.hip: sgg_halo_launch picks (default build)."""
@@ -429,7 +443,7 @@ class HipKernels:
         d = self._conv_dims(x.shape, w_hwio.shape, stride)
         assert tuple(y.shape) == (d[0], d[4], d[5], d[6]) and x.is_contiguous() and y.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
-        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_pc_symbol(ln is not None, x_s16) if w_split_layout == 4 else
+        sym = "conv_c3_fwd_kernel" if d[3] == 3 else (self.halo_pc_symbol(ln is not None, x_s16, d[6]) if w_split_layout == 4 else
                                                              self.halo_symbol(d[6], d[3], ln is not None) if w_split_layout == 1 else
                                                              self.halo_symbol(d[6], 4 * d[3], ln is not None) if w_split_layout == 3 else
                                                              self.s2_symbol(False, d[0] * d[4] * d[5], d[6], tile_stats is not None, ln is not None, x_s16) if w_split_layout == 2 else
@@ -451,7 +465,7 @@ class HipKernels:
         assert tuple(dy.shape) == (d[0], d[4], d[5], d[6]) and dy.is_contiguous() and dx.is_contiguous()
         flops = 2.0 * d[0] * d[4] * d[5] * d[6] * d[7] * d[8] * d[3]
         amax_dy, amax_w = self._amax_or_compute(dy, amax_dy, 0), self._amax_or_compute(w_hwio, amax_w, 1)
-        sym = self.halo_pc_symbol(False, dy_s16) if w_split_layout == 4 else self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
+        sym = self.halo_pc_symbol(False, dy_s16, d[3]) if w_split_layout == 4 else self.halo_symbol(d[3], d[6]) if w_split_layout == 1 else (self.halo_symbol(4 * d[3], d[6]) if w_split_layout == 3 else
                                                                           self.s2_symbol(True, d[0] * d[4] * d[5], d[3], False, False, dy_s16) if w_split_layout == 2 else
                                                                           self.gather_symbol(d[3], w_split is not None))
         self._check(self._timed(sym, flops, lambda: self.lib.sgg_conv2d_nhwc_dgrad(

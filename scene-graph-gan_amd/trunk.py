@@ -170,6 +170,21 @@ class Trunk:
             ho, wo = lay["out_shape"][1], lay["out_shape"][2]
             # (both directions are asked with the full-resolution grid: forward input = dgrad output)
             lay["ws_layout_bwd"] = K.conv_wsplit_layout(k, s, lay["hin"], lay["win"], lay["cout"], lay["cin"])
+            if lay["ws_layout_bwd"] == 1 and self._dy_presplit_static(lay) and hasattr(K, "conv_wsplit_layout_presplit"):
+                # the dgrad of a 64-column layer whose dy the LayerNorm backward writes pre-split (conv2_2, conv2_3): the four-block
+                # form of the producer / consumer kernel (patch by LDS-DMA only: the launch always passes dy_s16, backward())
+                lay["ws_layout_bwd"] = K.conv_wsplit_layout_presplit(k, s, lay["hin"], lay["win"], lay["cout"], lay["cin"])
+
+    def _dy_presplit_static(self, lay):
+        """Will _plan_s16 / backward() hand this layer's dgrad a PRE-SPLIT dy in every backward?  (The static conditions of
+        lay["dy_s16"] and of backward()'s nxt_s16: LayerNorm layer, fp16 two-piece mode with pre-split weights, the deferred LayerNorm
+        finalize, a resident filter gradient.)"""
+        K = self.K
+        if not (lay["has_ln"] and lay["cin"] != 3 and bool(getattr(K, "presplit", False)) and getattr(K, "conv_precision", 0) == 2
+                and hasattr(K, "wgrad_resident") and hasattr(K, "ln_bwd_finalize") and hasattr(K, "split_weights")):
+            return False
+        Bn, ho, wo, cout = lay["out_shape"]
+        return bool(K.wgrad_resident(Bn, ho, wo, lay["cin"], lay["cout"], lay["k"], lay["s"]))
 
     def _ln_prologue_expected(self, lay):
         """Will _plan_ln_fusion let this layer's forward apply the previous layer's LayerNorm + ELU in its patch staging, in either
@@ -273,7 +288,7 @@ class Trunk:
         K = self.K
         self._wver = getattr(self.arena, "version", 0)
         if hasattr(K, "prepare_weights"):
-            key = (K.conv_precision, getattr(K, "conv_halo", True))
+            key = (K.conv_precision, getattr(K, "conv_halo", True), bool(getattr(K, "presplit", False)), bool(getattr(K, "halo_pc64", True)))
             if getattr(self, "_wdesc_key", None) != key:       # layouts depend on the precision in force: rebuild the table
                 todo = []
                 for j, lay in enumerate(self.layers):
@@ -477,6 +492,7 @@ class Trunk:
                 assert ws is not None
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"], dy_s16=True)
             elif ws is not None or f16:
+                assert not (ws is not None and lay["ws_layout_bwd"] == 4 and lay["cin"] % 128), "four-block producer / consumer tiles need a pre-split dy"
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"], ws, self._am(1, j), self._am(2, j), lay["ws_layout_bwd"] if ws is not None else 0)
             else:
                 K.conv_dgrad(dy, lay["w"], dA, lay["s"])

@@ -352,3 +352,93 @@ def test_presplit_dy_bound_under_outlier_activations(mode2, ref, sigma):
         json.dump(allr, open(p, "w"), indent=1)
     assert k <= 11.0, "the bound leaves fewer than 5 of the 16 spare binades (k = %.2f)" % k
     assert e_b <= 2e-5 and e_b <= 2.0 * e_x + 3e-7, (e_b, e_x)
+
+
+PC64_CASES = [
+    # B, H, W, C (contraction channels), N = 64 output columns: the four-block form of the producer / consumer kernel
+    (2, 16, 16, 64),
+    (1, 8, 24, 128),        # three blocks: the fourth block of the only tile is dead
+    (3, 24, 40, 64),        # 45 blocks: a ragged last tile
+    (5, 8, 8, 256),         # 5 blocks in 2 tiles; eight chunks per tile
+    (32, 56, 56, 64),       # 1568 blocks = 392 tiles: 49 per XCD on 32 workgroups - several tiles per workgroup (conv2_2's dgrad shape)
+]
+
+
+@pytest.mark.parametrize("case", PC64_CASES)
+def test_producer_consumer_four_block_tiles(mode2, ref, case):
+    """conv_halo3_pc_kernel<true, false, true, 4> (round 5): 4 blocks x 64 columns per workgroup, reached through w_split_layout 4 with
+    Cout % 64 == 0 and a PRE-SPLIT source (sgg_conv_wsplit_layout_presplit).  Forward (bias, LayerNorm tile statistics) and dgrad
+    against fp64 and against the four-wave kernel on the same pieces (same products; the order inside a 32-channel chunk differs);
+    an f32 source with that layout must be refused."""
+    from sgg_amd.lib import SggError
+    hip = mode2
+    B, H, W, C = case
+    N = 64
+    assert hip.conv_wsplit_layout(3, 1, H, W, C, N) == 1 and hip.conv_wsplit_layout_presplit(3, 1, H, W, C, N) == 4
+    assert hip.conv_wsplit_layout_presplit(3, 1, H, W, C, 128) == 4 and hip.conv_wsplit_layout_presplit(3, 1, H, W, 32, N) == 1
+    x, w, b = rnd((B, H, W, C), 21), rnd((3, 3, C, N), 22, 1.0 / math.sqrt(9 * C)), rnd((N,), 23, 0.1)
+    # spikes on the image border: a halo lane that is not zeroed would multiply them
+    x[:, 0, :, :] *= 3.0
+    x[:, :, -1, :] *= 3.0
+    bx = 1.7 * float(x.abs().max())
+    am_x = torch.tensor([bx], device="cuda")
+    xq = from_s16(to_s16(x, bx), bx) if B * H * W * C <= (1 << 22) else None      # (the values the pieces represent: exact to 2^-22 of the bound)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    x16 = torch.empty_like(xd)
+    hip.presplit16(xd, x16, am_x)
+    am_w = torch.zeros(1, device="cuda")
+    hip.absmax(wd, am_w)
+    # ---- forward: y = conv(x, w) + b, N = 64 output columns ----
+    wf = torch.empty((3, 3, N, C), device="cuda")
+    hip.hwio_to_hwoi(wd, wf)
+    ws4, ws1 = (torch.empty((2, w.numel()), dtype=torch.int16, device="cuda") for _ in range(2))
+    hip.split_weights(wf, ws4, am_w, layout=4)
+    hip.split_weights(wf, ws1, am_w, layout=1)
+    nts = hip.conv_tile_stats_count((B, H, W, N), C, 3, 1, 4)
+    assert nts == H * W // 64
+    ts = torch.full((B, nts, 4), float("nan"), device="cuda")
+    y4 = torch.full((B, H, W, N), float("nan"), device="cuda")
+    hip.conv_fwd(x16, wd, wf, bd, y4, 1, ws4, am_x, am_w, ts, 4, x_s16=True)
+    y1 = torch.empty_like(y4)
+    hip.conv_fwd(x16, wd, wf, bd, y1, 1, ws1, am_x, am_w, None, 1, x_s16=True)
+    assert torch.isfinite(y4).all()
+    scale = float(y1.abs().max())
+    assert float((y4 - y1).abs().max()) <= 5e-6 * scale, "four-block producer / consumer forward vs the four-wave kernel"
+    if xq is not None:
+        y_ref = torch.empty((B, H, W, N), dtype=torch.float64)
+        ref.conv_fwd(xq.double(), w.double(), None, b.double(), y_ref, 1)
+        assert float((y4.cpu().double() - y_ref).abs().max()) <= 2e-5 * float(y_ref.abs().max())
+    g4, b4 = (1.0 + rnd((N,), 15, 0.2)).cuda(), rnd((N,), 16, 0.2).cuda()
+    a_t, a_p = torch.empty_like(y4), torch.empty_like(y4)
+    st_t, st_p = torch.empty((B, 2), device="cuda"), torch.empty((B, 2), device="cuda")
+    hip.ln_elu_fwd(y4, g4, b4, a_t, st_t, tile_stats=ts)
+    hip.ln_elu_fwd(y4, g4, b4, a_p, st_p)
+    # (mean: absolute against the sample's scale 1 / rstd; rstd: relative)
+    assert float((st_t[:, 0] - st_p[:, 0]).abs().max()) <= 1e-6 / float(st_p[:, 1].min()) and \
+        float(((st_t[:, 1] - st_p[:, 1]) / st_p[:, 1]).abs().max()) <= 1e-6, "tile statistics of the four-block epilogue vs the statistics pass"
+    # ---- dgrad: dx [.., 64] = conv-transpose of dy [.., C] with w [3,3,64,C] ----
+    w2 = rnd((3, 3, N, C), 24, 1.0 / math.sqrt(9 * C))
+    w2d = w2.cuda()
+    am_w2 = torch.zeros(1, device="cuda")
+    hip.absmax(w2d, am_w2)
+    wb4, wb1 = (torch.empty((2, w2.numel()), dtype=torch.int16, device="cuda") for _ in range(2))
+    hip.split_weights(w2d, wb4, am_w2, layout=4)
+    hip.split_weights(w2d, wb1, am_w2, layout=1)
+    assert hip.conv_wsplit_layout_presplit(3, 1, H, W, C, N) == 4      # (dgrad is asked with the channels swapped: contraction C, output N)
+    dx4 = torch.full((B, H, W, N), float("nan"), device="cuda")
+    hip.conv_dgrad(x16, w2d, dx4, 1, wb4, am_x, am_w2, 4, dy_s16=True)
+    dx1 = torch.empty_like(dx4)
+    hip.conv_dgrad(x16, w2d, dx1, 1, wb1, am_x, am_w2, 1, dy_s16=True)
+    assert torch.isfinite(dx4).all()
+    assert float((dx4 - dx1).abs().max()) <= 5e-6 * float(dx1.abs().max()), "four-block producer / consumer dgrad vs the four-wave kernel"
+    if xq is not None:
+        dx_ref = torch.empty((B, H, W, N), dtype=torch.float64)
+        ref.conv_dgrad(xq.double(), w2.double(), dx_ref, 1)
+        assert float((dx4.cpu().double() - dx_ref).abs().max()) <= 2e-5 * float(dx_ref.abs().max())
+    # twice the same launch: bit-identical
+    dx5 = torch.empty_like(dx4)
+    hip.conv_dgrad(x16, w2d, dx5, 1, wb4, am_x, am_w2, 4, dy_s16=True)
+    assert torch.equal(dx5, dx4)
+    # an f32 source has no four-block variant: refused, loudly
+    with pytest.raises(SggError):
+        hip.conv_dgrad(xd, w2d, dx5, 1, wb4, am_x, am_w2, 4)
