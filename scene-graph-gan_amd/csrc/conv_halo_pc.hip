@@ -38,6 +38,10 @@
 #ifndef PC_SPLIT_PRODUCERS
 #define PC_SPLIT_PRODUCERS 1
 #endif
+// ... and the same split for the register-staged patch (f32 sources, the LN prologue): 0 = four waves doing both (round 3)
+#ifndef PC_SPLIT_PRODUCERS_REG
+#define PC_SPLIT_PRODUCERS_REG 1
+#endif
 // s_waitcnt immediate of gfx9 for vmcnt(n) alone (expcnt, lgkmcnt: no wait): vmcnt low 4 bits in [3:0], its high 2 bits in [15:14]
 constexpr int pc_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
@@ -233,6 +237,188 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
           __builtin_amdgcn_s_barrier();                        // ... behind barrier 8
           cur ^= 1;
         }
+      return;
+    }
+    if constexpr (!DMAP && PC_SPLIT_PRODUCERS_REG) {
+      // ---- register-staged patch (f32 source, or the LN prologue on the producing layer's pre-LayerNorm y), roles split as above:
+      // waves 4, 5 the weight fragments; waves 6, 7 (128 threads) the patch - chunk c + 2 is LOADED at tap 0 of chunk c (two register
+      // sets), chunk c + 1 normalised / split and WRITTEN at taps 1 .. 7, one pass of 128 items per tap.  Their queue holds nothing but
+      // their own patch loads, which the compiler counts exactly: no wait for a weight fragment is a wait for a patch any more, and
+      // the prologue's arithmetic (v_exp, selects, the two-piece split) sits on two SIMDs whose consumer waves it delays by issue
+      // slots only.  (Round 5: this variant serves the forward-only passes that fuse LN4 / LN5, trunk.pc_ln_fusion_pays.)
+      static_assert(NB == 2, "register-staged patch: two-block tiles");
+      const unsigned w_slab2 = (unsigned)(p.N >> 5) * 4096u;
+      const float sa2 = ldexpf(1.f, ea);
+      if (pw < 2) {
+        constexpr int W2 = PC_SLOTB / 2048;
+        const unsigned w_lane2 = (unsigned)(n0 >> 5) * 4096u + (unsigned)pw * (unsigned)(PC_SLOTB / 2) + (unsigned)lane * 16u;
+        int d_cc = 0, d_tap = 0, d_slot = 0;
+        auto issue = [&]() __attribute__((always_inline)) {
+          const unsigned base = (unsigned)(d_tap * nch + d_cc) * w_slab2 + w_lane2;
+          unsigned char* dst = ring + d_slot * PC_SLOTB + pw * (PC_SLOTB / 2);
+#pragma unroll
+          for (int q = 0; q < W2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (pc_lds_ptr)(dst + q * 1024), 16, base + (unsigned)(q * 1024), 0, 0, 0);
+          if (++d_tap == 9) {
+            d_tap = 0;
+            if (++d_cc == nch) d_cc = 0;
+          }
+          d_slot = (d_slot + 1) & (PC_D - 1);
+        };
+#pragma unroll
+        for (int k = 0; k < PC_D; ++k) issue();
+        if constexpr (LNP) __builtin_amdgcn_s_barrier();      // (the patch waves' barrier behind the lnp_s fill)
+        __builtin_amdgcn_s_waitcnt(pc_vmcnt(0));
+        __builtin_amdgcn_s_barrier();             // barrier "-1"
+        for (int tile = mt_begin; tile < mt_end; tile += tstride)
+          for (int cc = 0; cc < nch; ++cc) {
+#pragma unroll
+            for (int T = 0; T < 9; ++T) {
+              __builtin_amdgcn_s_waitcnt(pc_vmcnt(2 * W2));
+              __builtin_amdgcn_s_barrier();
+              issue();
+            }
+          }
+        __builtin_amdgcn_s_waitcnt(pc_vmcnt(0));
+        return;
+      }
+      // ---- patch waves ----
+      const int pt2 = tid - 384;                  // 0 .. 127
+      constexpr int NP2 = (PC_ITEMS + 127) / 128; // 7 passes of 128 (block, patch pixel, 8-channel group) items
+      if constexpr (LNP) {
+        for (int c = pt2; c < p.ln_nc; c += 128) {
+          lnp_s[c] = p.ln_gamma[c];
+          lnp_s[512 + c] = p.ln_beta[c];
+        }
+      }
+      unsigned q_rel[NP2];
+      int q_meta[NP2];      // bits 0..19 LDS byte offset inside a plane, 20..23 border bits, 24 block, 26..27 channel group, 28 valid
+#pragma unroll
+      for (int j = 0; j < NP2; ++j) {
+        const int it = pt2 + 128 * j;
+        const int blk = (it / 400) & 1, r = it % 400;
+        const int px = r >> 2, ch8 = r & 3;
+        const int ry = px / 10, rx = px % 10;
+        q_rel[j] = (unsigned)((ry * p.in_rs + rx * p.in_ps + ch8 * 8) * 4);
+        const int bits = (ry == 0) | ((ry == 9) << 1) | ((rx == 0) << 2) | ((rx == 9) << 3);
+        q_meta[j] = (blk * PC_BLKB + (ry * PC_PITCH + rx) * 64 + ((ch8 ^ pc_sw(ry, rx)) << 4)) | (bits << 20) | (blk << 24) |
+                    (ch8 << 26) | ((it < PC_ITEMS) << 28);
+      }
+      float q_mu[2][PC_NB], q_rs[2][PC_NB];
+      int q_cc[2] = {0, 0}, q_bad[2] = {0, 0};
+      int s_grow[PC_NB], s_by[PC_NB], s_bx[PC_NB];
+#pragma unroll
+      for (int j = 0; j < PC_NB; ++j) {
+        const int beta = mt_begin * PC_NB + j;
+        s_grow[j] = beta / p.bw;
+        s_bx[j] = beta % p.bw;
+        s_by[j] = s_grow[j] % p.bh;
+      }
+      int s_tile = mt_begin, s_cc = 0;
+      f32x4 qre[2][NP2][2];
+      auto q_load = [&](auto s_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value;
+        unsigned base[PC_NB];
+        int bbits[PC_NB];
+#pragma unroll
+        for (int j = 0; j < PC_NB; ++j) {
+          const bool dead = (s_tile >= mt_end) | (s_tile * PC_NB + j >= p.nblk);
+          base[j] = (unsigned)(((s_grow[j] * 8 - 1) * p.in_rs + (s_bx[j] * 8 - 1) * p.in_ps + (s_cc >> 1) * p.in_cA + (s_cc & 1) * p.in_cB) * 4);
+          bbits[j] = dead ? 15 : ((s_by[j] == 0) | ((s_by[j] == p.bh - 1) << 1) | ((s_bx[j] == 0) << 2) | ((s_bx[j] == p.bw - 1) << 3));
+          if (dead) base[j] = SGG_OOB;
+        }
+        if constexpr (LNP) {
+          q_cc[S] = s_cc;
+          q_bad[S] = 0;
+#pragma unroll
+          for (int j = 0; j < PC_NB; ++j) {
+            int b = s_grow[j] / p.bh;
+            b = b < p.B ? b : p.B - 1;
+            q_mu[S][j] = p.ln_stats[2 * b];
+            q_rs[S][j] = p.ln_stats[2 * b + 1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) {
+          const int blk = (q_meta[j] >> 24) & 1;
+          const unsigned b0 = blk ? base[1] : base[0];
+          const int bb = blk ? bbits[1] : bbits[0];
+          const bool bad = !((q_meta[j] >> 28) & 1) | ((((q_meta[j] >> 20) & 15) & bb) != 0) | (b0 == SGG_OOB);
+          const unsigned off = bad ? SGG_OOB : b0 + q_rel[j];
+          if constexpr (LNP) q_bad[S] |= (int)bad << j;
+          const unsigned o0 = LNP ? off : stage_off0(off, p.src_s16);
+          qre[S][j][0] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, o0);
+          qre[S][j][1] = buf_load4_aux<SGG_PATCH_LOAD_AUX>(rs_src, LNP ? off + 16u : stage_off1(o0, p.src_s16));
+        }
+        if (++s_cc == nch) {        // advance to this workgroup's next tile
+          s_cc = 0;
+          s_tile += tstride;
+#pragma unroll
+          for (int j = 0; j < PC_NB; ++j) {
+            s_bx[j] += adv_cols;
+            s_grow[j] += adv_rows;
+            s_by[j] += adv_rows;
+            if (s_bx[j] >= p.bw) {
+              s_bx[j] -= p.bw;
+              ++s_grow[j];
+              ++s_by[j];
+            }
+            while (s_by[j] >= p.bh) s_by[j] -= p.bh;
+          }
+        }
+      };
+      // pass j of register set S: LN prologue (LNP), split, write into patch buffer dst
+      auto q_pass = [&](auto s_c, auto j_c, unsigned char* dst) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value, j = decltype(j_c)::value;
+        if constexpr (LNP) {
+          const int blk = (q_meta[j] >> 24) & 1;
+          const float mu = blk ? q_mu[S][1] : q_mu[S][0], rs = blk ? q_rs[S][1] : q_rs[S][0];
+          const int cb = ((q_cc[S] * 32) & (p.ln_nc - 1)) + ((q_meta[j] >> 26) & 3) * 8;
+          ln_elu8(qre[S][j][0], qre[S][j][1], lnp_s + cb, lnp_s + 512 + cb, mu, rs, (q_bad[S] >> j) & 1);
+        }
+        u32x4 pl[PC_P];
+        if constexpr (LNP || !HALF) split8<PC_P, HALF>(qre[S][j][0], qre[S][j][1], sa2, pl);
+        else stage_planes<PC_P, HALF>(qre[S][j][0], qre[S][j][1], sa2, p.src_s16, pl);
+        if (j < NP2 - 1 || ((q_meta[j] >> 28) & 1)) {
+#pragma unroll
+          for (int pp = 0; pp < PC_P; ++pp) *reinterpret_cast<u32x4*>(dst + pp * PC_PLANEB + (q_meta[j] & 0xfffff)) = pl[pp];
+        }
+      };
+      if constexpr (LNP) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // lnp_s is filled (matched by every other wave)
+      }
+      q_load(std::integral_constant<int, 0>{});   // chunk 0
+#define PC_QP(S, J, DST) q_pass(std::integral_constant<int, S>{}, std::integral_constant<int, J>{}, DST);
+      PC_QP(0, 0, lds) PC_QP(0, 1, lds) PC_QP(0, 2, lds) PC_QP(0, 3, lds) PC_QP(0, 4, lds) PC_QP(0, 5, lds) PC_QP(0, 6, lds)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      q_load(std::integral_constant<int, 1>{});   // chunk 1: in flight across the prologue barrier
+      __builtin_amdgcn_s_barrier();               // barrier "-1": patch 0 is in LDS
+      int cur = 0;
+      // one chunk c (register-set parity S = c & 1): chunk c + 2 -> set S at tap 0, chunk c + 1 (set S ^ 1) written at taps 1 .. 7
+      auto q_chunk = [&](auto s_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value;
+        unsigned char* nb = lds + (cur ^ 1) * PC_PATCHB;
+        q_load(s_c);
+        __builtin_amdgcn_s_barrier();             // tap 0
+        PC_QP(S ^ 1, 0, nb) __builtin_amdgcn_s_barrier();
+        PC_QP(S ^ 1, 1, nb) __builtin_amdgcn_s_barrier();
+        PC_QP(S ^ 1, 2, nb) __builtin_amdgcn_s_barrier();
+        PC_QP(S ^ 1, 3, nb) __builtin_amdgcn_s_barrier();
+        PC_QP(S ^ 1, 4, nb) __builtin_amdgcn_s_barrier();
+        PC_QP(S ^ 1, 5, nb) __builtin_amdgcn_s_barrier();
+        PC_QP(S ^ 1, 6, nb) __builtin_amdgcn_s_barrier();      // tap 7
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the next patch is written ...
+        __builtin_amdgcn_s_barrier();                          // ... behind barrier 8
+        cur ^= 1;
+      };
+#undef PC_QP_UNUSED
+      for (int tile = mt_begin; tile < mt_end; tile += tstride)
+        for (int cc = 0; cc < nch; cc += 2) {
+          q_chunk(std::integral_constant<int, 0>{});
+          q_chunk(std::integral_constant<int, 1>{});
+        }
+#undef PC_QP
       return;
     }
     const float sa = ldexpf(1.f, ea);

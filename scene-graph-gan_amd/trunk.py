@@ -68,6 +68,19 @@ def ln_fusion_pays(out_shape, cout_next):
     return saved > 1.5 * fwd_cost, cout_next != 64 and saved - fwd_cost - wgrad_cost > 10.0
 
 
+def pc_ln_fusion_pays(out_shape, cin_next, cout_next):
+    """Forward-only passes, consumer on the producer / consumer 3x3 kernel (which otherwise stages a pre-split a_j by LDS-DMA): does the
+    LN prologue - the consumer's register-staging variant with the prologue in its producer waves, ~340 against ~425 TFLOP/s - beat the
+    LayerNorm apply pass it saves (0.35 us per MB, ln_fusion_pays)?  Round 5, batch 64, two boxes (profiles/r05_ln_plan_ab*.log):
+    LN5 (411 MB in front of conv2_4) -0.19 ms per step, LN4 (205 MB in front of conv2_3) -0.09, both -0.2 ... -0.25; LN7 / LN8 (103 /
+    205 MB in front of conv3_1 / conv3_2, the same FLOPs behind a quarter / half of the bytes): none - which is what the two rates
+    predict (72 vs 70 us, 144 vs 139; 36 vs 70, 72 vs 139)."""
+    b, h, w, c = out_shape
+    mb = 4e-6 * b * h * w * c
+    flops = 2.0 * b * h * w * cout_next * 9 * cin_next
+    return 0.35 * mb > flops * (1.0 / 340e12 - 1.0 / 425e12) * 1e6
+
+
 class Trunk:
     def __init__(self, K, arena, grad_views, B, S):
         self.K, self.B, self.S = K, B, S
@@ -204,7 +217,8 @@ class Trunk:
         LDS-DMA and its filter gradient runs on the LDS-DMA kernel; an LN prologue would put both back on the register-staging
         kernels.  Measured with the prologue kept for these consumers: 45.29 / 45.20 against 45.09 / 45.16 ms per step without
         (profiles/r04_ln_fusion_plan_presplit_ab.log) - and the plain producer / consumer kernel is the faster kernel (0.50 of the
-        matrix peak against 0.43): those LayerNorms keep their apply pass."""
+        matrix peak against 0.43): those LayerNorms keep their apply pass - in passes with a backward always; in forward-only passes
+        except where pc_ln_fusion_pays says the saved pass is worth the slower variant (round 5: LN4, LN5)."""
         K = self.K
         return (bool(getattr(K, "presplit", False)) and getattr(K, "conv_precision", 0) == 2 and hasattr(K, "conv_wsplit_layout") and
                 K.conv_wsplit_layout(lay["k"], lay["s"], lay["hin"], lay["win"], lay["cin"], lay["cout"]) == 4)
@@ -242,7 +256,9 @@ class Trunk:
                 continue
             pays_fwd, pays_bwd = ln_fusion_pays(lay["out_shape"], nxt["cout"])
             if self._pc_presplit(nxt):
-                pays_fwd = pays_bwd = False
+                # consumer on the producer / consumer kernel: with a backward never (its filter gradient wants the pre-split a_j);
+                # forward-only where the apply pass it saves outweighs the consumer's slower prologue variant (pc_ln_fusion_pays)
+                pays_fwd, pays_bwd = pc_ln_fusion_pays(lay["out_shape"], nxt["cin"], nxt["cout"]), False
             if lay["i"] in getattr(K, "ln_fusion_skip", ()):      # (A/B option ln_fusion_skip of sgg_amd/lib.py)
                 pays_fwd = pays_bwd = False
             if lay["i"] in getattr(K, "ln_fusion_force", ()):     # (A/B option ln_fusion_force)

@@ -144,6 +144,11 @@ def test_ln_fusion_cost_model_decisions_at_configs1():
     assert [i for i, v in got.items() if v[0]] == [0, 1, 2, 3, 4, 5, 6, 7, 8]
     assert [i for i, v in got.items() if v[1]] == [0, 1, 4, 5, 6]
     assert ln_fusion_pays((8, 64, 64, 32), 32) == (False, False)            # small tensors: the flat overhead never pays
+    # consumers on the producer / consumer kernel (pre-split activations), forward-only passes: the prologue variant is ~20 % slower than
+    # the DMA-staged kernel, so only the LayerNorms whose apply pass moves enough bytes per consumer FLOP keep the fusion (round 5)
+    from sgg_amd.trunk import pc_ln_fusion_pays
+    pc = {4: ((64, 112, 112, 64), 64, 128), 5: ((64, 112, 112, 128), 128, 128), 7: ((64, 56, 56, 128), 128, 256), 8: ((64, 56, 56, 256), 256, 256)}
+    assert [i for i, a in pc.items() if pc_ln_fusion_pays(*a)] == [4, 5]
 
 
 def test_canvas_plan_for_odd_image_sizes():
