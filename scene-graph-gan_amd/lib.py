@@ -154,8 +154,8 @@ DEFAULT_OPTIONS = {
     # producer / consumer kernel (trunk._query_layouts; csrc/conv_halo_pc.hip NB = 4)
     "halo_pc64": True,
     # LayerNorm + ELU applied by the consuming convolution's patch staging (LN prologue): 1 (default) = per layer and per KIND of
-    # encoder pass (forward-only / followed by a backward) where trunk.ln_fusion_pays' measured cost model says it pays
-    # (trunk._plan_ln_fusion: with pre-split activations 16 of the 44 apply passes of a step at configs[1] run as prologues, 28 as
+    # encoder pass (forward-only / followed by a backward) where the measured cost models (trunk.ln_fusion_pays, pc_ln_fusion_pays) say it pays
+    # (trunk._plan_ln_fusion: with pre-split activations 20 of the 44 apply passes of a step at configs[1] run as prologues, 24 as
     # standalone passes - DESIGN.md "The LN prologue"); 2 = wherever the kernels allow (slower: DESIGN.md); 0 = never
     "ln_fusion": 1,
     # True: the LayerNorm kernels write their outputs pre-split for the convolutions that consume them (trunk._plan_s16; fp16 modes)
