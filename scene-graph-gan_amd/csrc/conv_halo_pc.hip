@@ -107,8 +107,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_pc_kernel(HaloParams p) {
     // patch of chunk c + 1 is split and WRITTEN at taps 1 .. 4 of chunk c: a load has at least ten taps to arrive before its first
     // use, and three before the first weight-DMA wait that covers it (vmcnt retires in order).  Weights: tap (d_cc, d_tap) of the
     // fragment stream -> ring slot by LDS-DMA, four of the tap's sixteen 1-KiB pieces per wave.
-    // (Two weight waves + two patch waves were measured too: equal without the LayerNorm prologue, 4 % slower with it - two waves
-    //  then carry all of its v_exp work.)
+    // That is the form every wave doing BOTH jobs takes (the code below the role branches; -DPC_SPLIT_PRODUCERS=0 /
+    // -DPC_SPLIT_PRODUCERS_REG=0).  Round 5 splits the four waves by ROLE instead - waves 4, 5 the weight fragments, waves 6, 7 the
+    // patch - in every variant: with both jobs in one queue the first wait for a weight fragment issued behind the patch loads is a
+    // wait for the whole patch.  (Round 3 had measured such a split 4 % slower with the LayerNorm prologue; with the weight waves'
+    // hand-counted vmcnt and the patch written one pass per tap it is the faster form there too: 346 -> 353 TFLOP/s, the step -0.17 ms,
+    // profiles/r05_split_producers_reg_ab.log.)
     // =================================================================================================================
     const int pt = tid - 256, pw = wave - 4;
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
