@@ -182,10 +182,6 @@ DEFAULT_OPTIONS = {
     # that dy, computes it itself (sgg_conv2d_nhwc_wgrad_c3_ln): one read of y and da instead of the apply pass (2 reads + 1 write of
     # 411 MB at batch 64) + the filter gradient's read of dy, on the tail of every encoder backward
     "c3_ln_bwd_fused": True,
-    # True: the optimiser step of the recurrent head's parameters (two thirds of a network's bytes) runs on the heads' deferred stream
-    # beside the encoder backward, as soon as their gradients are complete; the Adam launch at the end of the update - which the next
-    # forward waits for - covers the encoder's parameters only (step.GanStep._adam_head_early; bit-identical)
-    "adam_head_early": True,
     "d_side_cus": 0,      # the same for D's encoder forward on the side stream (beside G's forward and G's head)
     "fwd_cus": 0,         # the same for every encoder forward (16: G's and D's forwards of an update on disjoint halves of the chip)
     # cost-model overrides for A/B runs (conv indices): never fuse / fuse in forward-only passes / fuse in passes with backward /

@@ -78,28 +78,10 @@ class Network:
             self.pending = None
             self.adam_step(scale)
 
-    def adam_head_early(self, stream):
-        """The optimiser step of the recurrent head's parameters (everything behind the encoder in the arena: attention perceptron,
-        LSTM, decoder, D's embedding - two thirds of the bytes) on `stream`, as soon as their gradients are complete and nothing of
-        this update reads those parameters any more - i.e. behind head.finish_backward, beside the encoder backward - instead of in
-        the one Adam launch at the update's end, which the next forward waits for.  adam_step then covers the encoder's range only.
-        Elementwise, same step count: bit-identical.  (GanStep._adam_head_early: not with a gradient all-reduce in flight.)"""
-        a = self.arena
-        h0, n = a.offsets["attention_perceptron/kernel"], a.live_numel
-        assert not self.opt.get("head_done") and self.pending is None
-        with torch.cuda.stream(stream):
-            self.K.adam(a.flat[h0:n], self.grad_flat[h0:n], self.m_flat[h0:n], self.v_flat[h0:n],
-                        tf_adam_lr_t(self.adam_t + 1), ADAM_B1, ADAM_B2, ADAM_EPS, 1.0)
-        self.opt["head_done"] = True
-
     def adam_step(self, grad_scale=1.0):
         self.adam_t += 1
         a = self.arena
-        n = a.live_numel
-        if self.opt.get("head_done"):          # (adam_head_early took the head's range of this step)
-            assert grad_scale == 1.0
-            n, self.opt["head_done"] = a.offsets["attention_perceptron/kernel"], False
-        self.K.adam(a.flat[:n], self.grad_flat[:n], self.m_flat[:n], self.v_flat[:n],
+        self.K.adam(a.live(), a.live(self.grad_flat), a.live(self.m_flat), a.live(self.v_flat),
                     tf_adam_lr_t(self.adam_t), ADAM_B1, ADAM_B2, ADAM_EPS, grad_scale)
         a.version += 1                       # (encoders of other batch sizes on this arena re-derive their operand formats lazily)
         self.trunk.refresh_weights()
@@ -232,16 +214,6 @@ class GanStep:
             D.head.precompute(ctx)
         return ctx
 
-    def _adam_head_early(self, net):
-        """Option adam_head_early (default on; multi-stream schedule without data parallelism): Network.adam_head_early on the heads'
-        deferred stream, behind everything the main stream has enqueued (the last reader of the head's weights in an update is
-        finish_backward's attention dgrad) and behind the head's deferred parameter-gradient work (the same stream, program order);
-        head.join() in front of Network.update orders it before anything that follows.  With a gradient all-reduce (reducer) the whole
-        arena is reduced first and the optimiser step stays whole."""
-        if self.reducer is None and self.head_side is not None and getattr(self.K, "adam_head_early", 0) and net.pending is None:
-            self.head_side.wait_stream(torch.cuda.current_stream())
-            net.adam_head_early(self.head_side)
-
     def _join_side(self):
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
@@ -296,7 +268,6 @@ class GanStep:
         D.head.backward(st2, ctx, u2, R_w=B)
         # W enters g = delta_e @ W^T directly as well: handled by the tangent input v @ W above (u2[1])
         dctx = D.head.finish_backward(ctx)
-        self._adam_head_early(D)
         D.trunk.backward(dctx)
         D.head.join()
         D.update(self.reducer)
@@ -359,7 +330,6 @@ class GanStep:
             K.gemm_nt(st.dXH[t][0][:, FEAT_C:ind], D.head.W_emb, gst.dOUT[0][:, t, :])
         G.head.backward(gst, gctx, None, R_w=B)
         dctx = G.head.finish_backward(gctx)
-        self._adam_head_early(G)
         G.trunk.backward(dctx)
         G.head.join()
         G.update(self.reducer)
