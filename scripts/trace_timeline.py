@@ -1,5 +1,7 @@
-"""Where a two-stream step spends its time: python scripts/trace_timeline.py <kernel_trace.csv> [n_last_steps]
-(rocprofv3 --kernel-trace --output-format csv of `bench.py --steps N ...`).  Kernels are classed as MFMA-bound convolution work or
+"""Where a two-stream step spends its time: python scripts/trace_timeline.py <kernel_trace.csv> [n_last_steps] [--gated] [--gantt]
+(rocprofv3 --kernel-trace --output-format csv of `bench.py --steps N ...`; --gated: of scripts/trace_step.py, whose steps are
+delimited by GPU-side spin kernels - the window is the LAST step, from the end of its spin to its last kernel; --gantt: also list
+every kernel of the last step longer than 15 us with its queue).  Kernels are classed as MFMA-bound convolution work or
 "other" (LayerNorm, heads, optimiser, ...); the union of their [start, end) intervals over the last steps of the trace gives the time
 with a matrix kernel resident, with only other kernels resident, and with nothing resident, and the kernels that fill the
 matrix-idle time."""
@@ -7,18 +9,25 @@ import csv
 import sys
 from collections import defaultdict
 
-path = sys.argv[1]
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+gated, gantt = "--gated" in sys.argv, "--gantt" in sys.argv
+path = argv[0]
 rows = []
-for r in csv.DictReader(open(path)):
+import gzip
+for r in csv.DictReader(gzip.open(path, "rt") if path.endswith(".gz") else open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
 rows.sort()
 mfma = lambda n: n.startswith("void conv_") and "c3" not in n and "slab_reduce" not in n
 # the timed window: from the first Adam launch of the last `nsteps` steps ... simply the last fraction of the trace by Adam launches
 adam = [i for i, r in enumerate(rows) if r[2].startswith("adam_kernel")]
-nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+nsteps = int(argv[1]) if len(argv) > 1 else 3
 lo = rows[adam[-2 * nsteps - 1]][1] if len(adam) > 2 * nsteps else rows[0][0]
 hi = rows[adam[-1]][1]
-win = [r for r in rows if r[0] >= lo and r[1] <= hi]
+if gated:
+    spins = [i for i, r in enumerate(rows) if "spin_kernel" in r[2]]
+    nsteps, lo = 1, rows[spins[-1]][1]
+    hi = max(r[1] for r in rows[spins[-1] + 1:])
+win = [r for r in rows if r[0] >= lo and r[1] <= hi and "spin_kernel" not in r[2]]
 
 
 def union(iv):
@@ -63,7 +72,7 @@ for n, v in sorted(acc.items(), key=lambda kv: -kv[1])[:25]:
     print("    %-72s %6.3f" % (n, v / 1e6 / nsteps))
 
 # ---- the matrix-idle intervals of ONE step (the last one), longest first: where in the schedule the matrix pipe has nothing -------
-step_lo = rows[adam[-3]][1] if len(adam) > 3 else lo
+step_lo = lo if gated else (rows[adam[-3]][1] if len(adam) > 3 else lo)
 gaps = []
 prev = step_lo
 for c, d in um:
@@ -92,3 +101,9 @@ for a, b in top:
     print("    +%7.3f ms  %7.1f us (busy %6.1f)  after %-40s before %-40s : %s"
           % ((a - step_lo) / 1e6, (b - a) / 1e3, busy, name(before[-1]) if before else "-", name(after[0]) if after else "-",
              ", ".join("%s x%d %.0fus" % (k, v[0], v[1]) for k, v in sorted(inside.items(), key=lambda kv: -kv[1][1])[:5])))
+
+if gantt:
+    print("  kernels of the last step longer than 15 us (start, end in ms from the step's start; us; queue):")
+    for a, b, n, q in win:
+        if a >= step_lo and b - a > 15000:
+            print("    %8.3f %8.3f %6.0f q%s %s" % ((a - step_lo) / 1e6, (b - step_lo) / 1e6, (b - a) / 1e3, q, n.replace("void ", "").split("(")[0][:64]))
