@@ -40,6 +40,12 @@ extern "C" int sgg_device_info(int* cu_count, size_t* lds_bytes_per_cu, size_t* 
 __global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
+// 16-byte stores (p 16-byte aligned, n4 = n / 4): the gradient arenas (138 MB, zeroed at the start of every update on the chain of
+// that update's first encoder forward) took 86 us with 4-byte stores
+__global__ void fill4_kernel(f32x4* __restrict__ p, long long n4, float v) {
+  const f32x4 vv = f32x4{v, v, v, v};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) p[i] = vv;
+}
 
 // out[b, :] = real[b, :] + alpha[b] * (fake[b, :] - real[b, :])
 __global__ void interpolate_kernel(const float* __restrict__ real, const float* __restrict__ fake, const float* __restrict__ alpha,
@@ -216,7 +222,13 @@ extern "C" int sgg_absmax(const float* x, long long n, float* amax, void* stream
 extern "C" int sgg_fill(float* p, long long n, float value, void* stream) {
   SGG_CHECK_ARG(p && n >= 0, "sgg_fill: bad argument");
   if (n == 0) return SGG_OK;
-  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  if (n >= 4096 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(fill4_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4*>(p), n4, value);
+    if (n & 3) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p + 4 * n4, n & 3, value);
+  } else {
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  }
   SGG_LAUNCH_CHECK("sgg_fill");
   return SGG_OK;
 }
