@@ -41,6 +41,8 @@ def _snapshot(gs):
 
 
 def test_step_is_unchanged_beside_mfma_kernels_of_another_stream(hip):
+    if not getattr(hip, "conv_halo", True):
+        pytest.skip("SGG_OPTIONS=conv_halo=0: the aggressor of this test is the resident MFMA kernels' staging variant")
     img, lab, noise0, noise1, alpha = _inputs()
     side = torch.cuda.Stream()
     agg = _new_step(hip)                       # an independent network: operands of the kernels that run beside
